@@ -1,0 +1,73 @@
+"""config.yaml loader keeping the reference's schema (config.yaml:13-94) without hydra/omegaconf.
+
+The reference resolves its config with hydra (main.py:40); neither hydra nor omegaconf is needed for the hot path,
+so the same yaml is read with PyYAML into an attribute dict.  An optional ``runtime`` section (ours) carries what
+the reference hard-codes in main.py:42-50 (number of environments, seed, ...).
+"""
+import copy
+import os
+
+import yaml
+
+SECTIONS = ("env", "sensor", "map", "attacker", "defender", "algo")
+
+
+class Cfg(dict):
+    """dict with attribute access, like the omegaconf nodes the reference code reads (cfg.env.max_steps ...)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return Cfg({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def to_cfg(d):
+    if isinstance(d, dict):
+        return Cfg({k: to_cfg(v) for k, v in d.items()})
+    return d
+
+
+DEFAULT_YAML = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config.yaml")
+
+
+def load_config(path=None, **overrides):
+    """Reads a reference-schema config.yaml.  ``overrides`` are dotted keys, e.g. ``**{"env.num_defender": 8}``."""
+    raw = yaml.safe_load(open(path or DEFAULT_YAML))
+    cfg = to_cfg({k: raw[k] for k in SECTIONS if k in raw})
+    cfg["runtime"] = to_cfg(raw.get("runtime") or {})
+    rt = cfg.runtime
+    rt.setdefault("num_envs", 16)
+    rt.setdefault("seed", 0)
+    rt.setdefault("tape_len", 16)
+    rt.setdefault("max_path", 128)
+    rt.setdefault("reference_quirks", True)
+    for k, v in overrides.items():
+        node = cfg
+        parts = k.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg
+
+
+def baseline_config(name="cfg2", **overrides):
+    """The concrete configurations of BASELINE.json / SURVEY 8d."""
+    base = {
+        "cfg1": {"env.num_defender": 4, "map.map_size": [20, 20], "map.center": [10, 10], "map.variance": 4,
+                 "map.num_obstacle_block": 2, "algo.depth": 1, "runtime.num_envs": 16},
+        "cfg2": {"env.num_defender": 8, "map.map_size": [40, 40], "map.center": [20, 20], "map.variance": 10,
+                 "map.num_obstacle_block": 5, "algo.depth": 0, "runtime.num_envs": 4096},
+        "cfg3": {"env.num_defender": 8, "map.map_size": [40, 40], "map.center": [20, 20], "map.variance": 10,
+                 "map.num_obstacle_block": 5, "algo.depth": 3, "runtime.num_envs": 4096},
+    }[name]
+    ov = dict(base)
+    ov["algo.use_reward_norm"] = True  # the shipped `false` crashes the reference's run_episode
+    ov.update(overrides)
+    return load_config(**ov)

@@ -1,0 +1,673 @@
+// pe_env.hip -- batched pursuit-evasion environment for MI355X (gfx950 / CDNA4).  C ABI: include/pe_env.h.
+//
+// One 64-lane wavefront (= one workgroup) owns one environment.  The environment's record (occupancy grid,
+// boundary-index map, agent state) is contiguous in HBM, so every global access of the wave is coalesced by
+// construction; grid + boundary-index map + agent state are staged once per launch in LDS and all neighbour /
+// obstacle / line-of-sight / LiDAR / A* lookups run out of LDS.  Launches keep the block -> environment map
+// fixed (block b == environment b), and blocks b, b+8, ... share an XCD, so an environment's record stays in
+// the same XCD's L2 from tick to tick.
+//
+// Numerics: environment state is f64.  Build with -ffp-contract=off: the only fused multiply-add is the
+// explicit one inside norm2(), which mirrors how numpy evaluates np.linalg.norm of a 2-vector in the
+// reference.  Rounding to cells uses round-half-even (Python round), int() truncates.
+//
+// Reference citations (paths relative to the reference root) are given per function.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "pe_env.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr double SQRT2 = 0x1.6a09e667f3bcdp+0;  // math.hypot(1, 1)  (astar.py:96)
+
+__device__ __forceinline__ int py_round(double v) { return (int)__builtin_rint(v); }
+__device__ __forceinline__ double norm2(double a, double b) { return __builtin_sqrt(__builtin_fma(b, b, a * a)); }
+
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }  // one wave per workgroup: LDS visibility fence
+
+struct Lds {
+    uint8_t *grid;   // [W*H]
+    int16_t *bidx;   // [W*H]
+    double *def;     // [4][P]
+    double *prop;    // [4][P]
+    double *eva;     // [4]
+    float *oadj;     // [P*O]
+    uint8_t *cond;   // [P*P]
+    int32_t *misc;   // [16]
+    // replan scratch
+    uint8_t *obs;    // [(W+1)*(H+1)]
+    uint8_t *open;   // [(W+1)*(H+1)]
+    uint16_t *parent;  // [(W+1)*(H+1)]
+    double *g;       // [(W+1)*(H+1)]
+};
+
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+__host__ __device__ inline size_t lds_layout(const pe_config &c, bool with_obs, bool with_replan, unsigned char *base, Lds *l) {
+    const int WH = c.W * c.H, P = c.P, NN = (c.W + 1) * (c.H + 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    size_t o_g = take(sizeof(double) * (with_replan ? NN : 0));
+    size_t o_def = take(sizeof(double) * 4 * P);
+    size_t o_prop = take(sizeof(double) * 4 * P);
+    size_t o_eva = take(sizeof(double) * 4);
+    size_t o_oadj = take(sizeof(float) * (with_obs ? P * c.O : 0));
+    size_t o_misc = take(sizeof(int32_t) * 16);
+    size_t o_bidx = take(sizeof(int16_t) * (with_obs ? WH : 0));
+    size_t o_parent = take(sizeof(uint16_t) * (with_replan ? NN : 0));
+    size_t o_grid = take(WH);
+    size_t o_cond = take(P * P);
+    size_t o_obs = take(with_replan ? NN : 0);
+    size_t o_open = take(with_replan ? NN : 0);
+    if (l) {
+        l->g = (double *)(base + o_g);
+        l->def = (double *)(base + o_def);
+        l->prop = (double *)(base + o_prop);
+        l->eva = (double *)(base + o_eva);
+        l->oadj = (float *)(base + o_oadj);
+        l->misc = (int32_t *)(base + o_misc);
+        l->bidx = (int16_t *)(base + o_bidx);
+        l->parent = (uint16_t *)(base + o_parent);
+        l->grid = base + o_grid;
+        l->cond = base + o_cond;
+        l->obs = base + o_obs;
+        l->open = base + o_open;
+    }
+    return off;
+}
+
+// ---- coalesced copies between HBM records and LDS ------------------------------------------------------
+__device__ __forceinline__ void copy_in(void *dst, const void *src, int nbytes, int lane) {
+    if ((nbytes & 15) == 0 && (((uintptr_t)src) & 15) == 0) {
+        const uint4 *s = (const uint4 *)src;
+        uint4 *d = (uint4 *)dst;
+        for (int i = lane; i < (nbytes >> 4); i += WAVE) d[i] = s[i];
+    } else if ((nbytes & 3) == 0 && (((uintptr_t)src) & 3) == 0) {
+        const uint32_t *s = (const uint32_t *)src;
+        uint32_t *d = (uint32_t *)dst;
+        for (int i = lane; i < (nbytes >> 2); i += WAVE) d[i] = s[i];
+    } else {
+        const uint8_t *s = (const uint8_t *)src;
+        uint8_t *d = (uint8_t *)dst;
+        for (int i = lane; i < nbytes; i += WAVE) d[i] = s[i];
+    }
+}
+__device__ __forceinline__ void copy_out_f32(float *dst, const float *src, int n, int lane) {
+    if ((n & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        const float4 *s = (const float4 *)src;
+        float4 *d = (float4 *)dst;
+        for (int i = lane; i < (n >> 2); i += WAVE) d[i] = s[i];
+    } else {
+        for (int i = lane; i < n; i += WAVE) dst[i] = src[i];
+    }
+}
+
+// ---- agent.py:74-104 : first-order lag integrated with RK4, association exactly as written -------------
+__device__ __forceinline__ void dynamic(double tau, double h, double x, double y, double vx0, double vy0, double ux, double uy,
+                                        double *o) {
+    double k1 = (ux - vx0) / tau;
+    double k2 = (ux - (vx0 + h * k1 / 2)) / tau;
+    double k3 = (ux - (vx0 + h * k2 / 2)) / tau;
+    double k4 = (ux - (vx0 + h * k3)) / tau;
+    double vx = vx0 + (k1 + 2 * k2 + 2 * k3 + k4) * h / 6;
+    k1 = (uy - vy0) / tau;
+    k2 = (uy - (vy0 + h * k1 / 2)) / tau;
+    k3 = (uy - (vy0 + h * k2 / 2)) / tau;
+    k4 = (uy - (vy0 + h * k3)) / tau;
+    double vy = vy0 + (k1 + 2 * k2 + 2 * k3 + k4) * h / 6;
+    o[0] = x + vx * h;
+    o[1] = y + vy * h;
+    o[2] = vx;
+    o[3] = vy;
+}
+
+__device__ __forceinline__ bool in_bound_i(const pe_config &c, int x, int y) { return x < c.W && x >= 0 && y < c.H && y >= 0; }
+
+// ---- defenders: Pursuit_Env.step + defender_reward + collision_detection (pursuit_env.py:104-177) ------
+__device__ void dev_step(const pe_config &c, const Lds &l, int lane, const int32_t *actions, int32_t *meta, double *rn,
+                         double *def_hbm, const pe_step_out &out, int env) {
+    const int P = c.P;
+    if (lane < P) {
+        int a = actions[lane];
+        a = a < 0 ? 0 : (a > 8 ? 8 : a);
+        double o[4];
+        dynamic(c.def_tau, c.def_dt, l.def[lane], l.def[P + lane], l.def[2 * P + lane], l.def[3 * P + lane], c.action_u[a][0],
+                c.action_u[a][1], o);
+        l.prop[lane] = o[0]; l.prop[P + lane] = o[1]; l.prop[2 * P + lane] = o[2]; l.prop[3 * P + lane] = o[3];
+    }
+    wave_sync();
+    const double r = c.def_collision_radius;
+    const double ex = l.eva[0], ey = l.eva[1];
+    int my_rew = 0, my_ok = 0, any_coll = 0;
+    for (int i = 0; i < P; i++) {  // sequential in the agent index: proposals are clipped in place
+        const double sx = l.prop[i], sy = l.prop[P + i];
+        // inner collisions against the current (possibly already clipped) proposals, self included
+        bool near = (lane < P) && (norm2(l.prop[lane] - sx, l.prop[P + lane] - sy) <= r);
+        int cnt = __popcll(__ballot(near));
+        // 3x3 probe of the static map at half-radius offsets; only in-bound probes count (pursuit_env.py:152-163)
+        bool hit = false;
+        if (lane < 9) {
+            int a = lane / 3 - 1, b = lane % 3 - 1;
+            double qx = sx + (double)a * r, qy = sy + (double)b * r;
+            int ix = py_round(qx), iy = py_round(qy);
+            if (in_bound_i(c, ix, iy)) hit = l.grid[ix * c.H + iy] != 0;
+        }
+        int col = __ballot(hit) != 0ull;
+        int rew = -(cnt - 1) - col;
+        int ok = 0;
+        if (rew < 0) {
+            any_coll = 1;
+        } else {
+            double cx = sx < 0.0 ? 0.0 : (sx > (double)(c.W - 1) ? (double)(c.W - 1) : sx);
+            double cy = sy < 0.0 ? 0.0 : (sy > (double)(c.H - 1) ? (double)(c.H - 1) : sy);
+            if (lane == 0) { l.prop[i] = cx; l.prop[P + i] = cy; }
+            if (norm2(ex - cx, ey - cy) <= r) rew += 1;
+            ok = 1;
+        }
+        if (lane == i) { my_rew = rew; my_ok = ok; }
+        wave_sync();
+    }
+    if (lane < P) {
+        if (my_ok) {
+            double nx = l.prop[lane], ny = l.prop[P + lane], nvx = l.prop[2 * P + lane], nvy = l.prop[3 * P + lane];
+            l.def[lane] = nx; l.def[P + lane] = ny; l.def[2 * P + lane] = nvx; l.def[3 * P + lane] = nvy;
+            def_hbm[lane] = nx; def_hbm[P + lane] = ny; def_hbm[2 * P + lane] = nvx; def_hbm[3 * P + lane] = nvy;
+        }
+        // DHGN/normalization.py:12-35 : per-environment running mean/std of the reward vector
+        double x = (double)my_rew, outv = x;
+        if (c.use_reward_norm) {
+            double n = rn[0] + 1.0;
+            if (n == 1.0) {
+                rn[1 + lane] = x;
+                outv = (x - x) / (x + 1e-8);
+            } else {
+                double old = rn[1 + lane];
+                double mean = old + (x - old) / n;
+                double S = rn[1 + P + lane] + (x - old) * (x - mean);
+                rn[1 + lane] = mean;
+                rn[1 + P + lane] = S;
+                outv = (x - mean) / (__builtin_sqrt(S / n) + 1e-8);
+            }
+        }
+        if (out.reward) out.reward[(int64_t)env * out.reward_stride + lane] = (float)outv;
+        if (out.reward_raw) out.reward_raw[(int64_t)env * out.reward_raw_stride + lane] = (float)my_rew;
+    }
+    wave_sync();
+    if (lane == 0) {
+        if (c.use_reward_norm) rn[0] = rn[0] + 1.0;
+        int t = meta[PE_META_T] + 1;
+        meta[PE_META_T] = t;
+        l.misc[0] = t;
+        if (any_coll) meta[PE_META_COLLISION] = 1;
+        if (out.done) out.done[env] = (uint8_t)(t >= c.max_steps);
+    }
+    wave_sync();
+}
+
+// ---- observations: get_state, communicate, sensor (base_env.py:198-209, pursuit_env.py:182-209) --------
+__device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env, const pe_obs_out &o, int n_obs) {
+    const int P = c.P, O = c.O;
+    if (o.p_state && lane < 4 * P) o.p_state[(int64_t)env * o.p_state_stride + lane] = (float)l.def[(lane & 3) * P + (lane >> 2)];
+    if (o.e_state && lane < 4) o.e_state[(int64_t)env * o.e_state_stride + lane] = (float)l.eva[lane];
+    // communicate(): upper-triangular range test plus the adj[j, 1] = 1 side effect
+    for (int idx = lane; idx < P * P; idx += WAVE) {
+        int i = idx / P, j = idx - i * P;
+        l.cond[idx] = (i <= j) && (norm2(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= c.def_comm_range);
+    }
+    for (int idx = lane; idx < P * O; idx += WAVE) l.oadj[idx] = 0.f;
+    wave_sync();
+    if (o.p_adj) {
+        for (int idx = lane; idx < P * P; idx += WAVE) {
+            int i = idx / P, j = idx - i * P;
+            bool v = l.cond[idx] != 0;
+            if (j == 1) {  // adj[i, 1] is set whenever some row k <= i is in range of i (k == i always is)
+                for (int k = 0; k <= i; k++) v = v || (l.cond[k * P + i] != 0);
+            }
+            o.p_adj[(int64_t)env * o.p_adj_stride + idx] = v ? 1.f : 0.f;
+        }
+    }
+    // find_attacker(): rounded-cell range test + Bresenham line of sight over the static map (agent.py:157-169, 319-341)
+    if (o.e_adj && lane < P) {
+        int x0 = py_round(l.def[lane]), y0 = py_round(l.def[P + lane]);
+        int x1 = py_round(l.eva[0]), y1 = py_round(l.eva[1]);
+        float seen = 0.f;
+        if (!(norm2((double)(x0 - x1), (double)(y0 - y1)) > c.def_sen_range)) {
+            int dx = abs(x1 - x0), dy = abs(y1 - y0);
+            int sx = x0 > x1 ? -1 : 1, sy = y0 > y1 ? -1 : 1;
+            int err = dx - dy;
+            seen = 1.f;
+            for (int it = 0; it < 4 * (c.W + c.H); it++) {  // bounded: the line has at most dx+dy+1 cells
+                if (l.grid[x0 * c.H + y0] == 1) { seen = 0.f; break; }
+                if (x0 == x1 && y0 == y1) break;
+                int e2 = 2 * err;
+                if (e2 > -dy) { err -= dy; x0 += sx; }
+                if (e2 < dx) { err += dx; y0 += sy; }
+            }
+        }
+        o.e_adj[(int64_t)env * o.e_adj_stride + lane] = seen;
+    }
+    // LiDAR from the truncated cell of every defender (pursuit_env.py:29-53, :201): beams x ranges out of LDS
+    if (o.o_adj) {
+        const int tasks = P * c.num_beams;
+        for (int task = lane; task < tasks; task += WAVE) {
+            int i = task / c.num_beams, b = task - i * c.num_beams;
+            int cx = (int)l.def[i], cy = (int)l.def[P + i];
+            double bx = c.beam_dir[b][0], by = c.beam_dir[b][1];
+            for (int r = 0; r < c.lidar_radius; r++) {
+                double px = (double)cx + (double)r * bx;
+                double py = (double)cy + (double)r * by;
+                if (px < 0 || px >= (double)c.W || py < 0 || py >= (double)c.H) break;
+                int id = l.bidx[(int)px * c.H + (int)py];
+                if (id >= 0) {
+                    if (id < O && id < n_obs) l.oadj[i * O + id] = 1.f;
+                    break;
+                }
+            }
+        }
+        wave_sync();
+        copy_out_f32(o.o_adj + (int64_t)env * o.o_adj_stride, l.oadj, P * O, lane);
+    }
+    wave_sync();
+}
+
+// ---- weighted A* (astar.py:26-161) on an LDS-resident problem ------------------------------------------
+// OPEN is a per-node flag; the pop is a wave-wide arg-min of (f, x, y) over open nodes, which is the order
+// heapq yields for (f, (x, y)) tuples.  Stale duplicates of the reference's heap never change g/PARENT when
+// popped (same g, same sums), so keeping only the live entry per node is equivalent.
+// Returns the true path length (goal -> start); stores the last min(len, max_path) nodes in path_out (HBM).
+__device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, int gx, int gy, int16_t *path_out, int max_path,
+                         int *n_stored, int *n_expanded, int *status) {
+    const int SY = H + 1, NN = (W + 1) * SY;
+    const int s_id = sx * SY + sy, g_id = gx * SY + gy;
+    *n_expanded = 0;
+    if (l.obs[g_id]) {  // astar.py:46-47
+        if (lane == 0) { path_out[0] = (int16_t)sx; path_out[1] = (int16_t)sy; }
+        *n_stored = 1;
+        return 1;
+    }
+    for (int i = lane; i < NN; i += WAVE) { l.g[i] = __builtin_inf(); l.open[i] = 0; l.parent[i] = 0xFFFF; }
+    wave_sync();
+    if (lane == 0) {
+        l.parent[s_id] = (uint16_t)s_id;
+        l.g[s_id] = (s_id == g_id) ? __builtin_inf() : 0.0;  // astar.py:39-40: g[goal] = inf overrides g[start]
+        l.open[s_id] = 1;
+    }
+    wave_sync();
+    const int cap = 16 * NN;  // every wave leaves the loop: the open set drains or the cap trips
+    int expanded = 0;
+    for (int it = 0; it < cap; it++) {
+        // --- pop: arg-min over open nodes of (f = g + 2.5 * manhattan, id) ; id order == (x, y) tuple order
+        double bf = __builtin_inf();
+        int bid = -1;
+        for (int i = lane; i < NN; i += WAVE) {
+            if (l.open[i]) {
+                int x = i / SY, y = i - x * SY;
+                double f = l.g[i] + 2.5 * (double)(abs(gx - x) + abs(gy - y));
+                if (bid < 0 || f < bf || (f == bf && i < bid)) { bf = f; bid = i; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            double of = __shfl_xor(bf, off);
+            int oid = __shfl_xor(bid, off);
+            if (oid >= 0 && (bid < 0 || of < bf || (of == bf && oid < bid))) { bf = of; bid = oid; }
+        }
+        if (bid < 0) break;  // OPEN empty
+        expanded++;
+        if (bid == g_id) break;
+        const int cx = bid / SY, cy = bid - cx * SY;
+        const double gc = l.g[bid];
+        const bool cur_blocked = l.obs[bid] != 0;  // is_collision(s_start=cur, .) (astar.py:106-107)
+        wave_sync();
+        if (lane == 0) l.open[bid] = 0;
+        if (lane < 8 && !cur_blocked) {
+            // u_set order (-1,0),(-1,1),(0,1),(1,1),(1,0),(1,-1),(0,-1),(-1,-1) (astar.py:11-12); neighbours are distinct
+            const int ux = (lane < 2 || lane == 7) ? -1 : ((lane >= 3 && lane <= 5) ? 1 : 0);
+            const int uy = (lane >= 1 && lane <= 3) ? 1 : ((lane >= 5) ? -1 : 0);
+            int nx = cx + ux, ny = cy + uy;
+            if (nx >= 0 && nx <= W && ny >= 0 && ny <= H) {  // '>' bounds: x == W and y == H are legal (astar.py:109-113)
+                int nid = nx * SY + ny;
+                if (!l.obs[nid]) {
+                    double nc = gc + ((ux != 0 && uy != 0) ? SQRT2 : 1.0);
+                    if (nc < l.g[nid]) { l.g[nid] = nc; l.parent[nid] = (uint16_t)bid; l.open[nid] = 1; }
+                }
+            }
+        }
+        wave_sync();
+        if (it == cap - 1) *status |= PE_STATUS_ASTAR_CAP;
+    }
+    *n_expanded = expanded;
+    // extract_path (astar.py:130-146); KeyError -> [s_start] (astar.py:67-71)
+    int len = 1;
+    if (l.parent[g_id] == 0xFFFF) {
+        if (lane == 0) { path_out[0] = (int16_t)sx; path_out[1] = (int16_t)sy; }
+        *n_stored = 1;
+        return 1;
+    }
+    {
+        int s = g_id;
+        for (int k = 0; k < NN + 1; k++) { s = l.parent[s]; len++; if (s == s_id) break; }
+    }
+    const int cnt = len < max_path ? len : max_path;
+    if (lane == 0) {
+        int s = g_id, k = 0;
+        const int skip = len - cnt;
+        for (;;) {
+            if (k >= skip) { path_out[2 * (k - skip)] = (int16_t)(s / SY); path_out[2 * (k - skip) + 1] = (int16_t)(s % SY); }
+            k++;
+            if (k >= len) break;
+            s = l.parent[s];
+        }
+    }
+    *n_stored = cnt;
+    return len;
+}
+
+// ---- Evader.replan + rescan (agent.py:202-259, Occupied_Grid_Map.py:119-191) ----------------------------
+__device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int32_t *meta, int16_t *path, const int32_t *target) {
+    const int W = c.W, H = c.H, P = c.P, SY = H + 1, NN = (W + 1) * SY;
+    const int sx = py_round(l.eva[0]), sy = py_round(l.eva[1]);
+    const int gx = target[0], gy = target[1];
+    int ext = c.extend_dis;
+    int len = 1, cnt = 1, total_exp = 0, status = 0;
+    while (ext >= 0) {
+        // OBS = static U inflate(static, ext) U {visible cells that only the defender-augmented map blocks}
+        const int vr = c.evader_view;
+        for (int i = lane; i < NN; i += WAVE) {
+            int x = i / SY, y = i - x * SY;
+            uint8_t v = 0;
+            if (x < W && y < H) {
+                bool dyn = false;
+                for (int xx = x - ext; xx <= x + ext; xx++)
+                    for (int yy = y - ext; yy <= y + ext; yy++)
+                        if (in_bound_i(c, xx, yy) && l.grid[xx * H + yy]) dyn = true;
+                v = dyn;
+                if (!dyn) {
+                    int dx = sx - x, dy = sy - y;
+                    bool visible = (x >= sx - vr) && (x < sx + vr) && (y >= sy - vr) && (y < sy + vr) &&
+                                   (norm2((double)dx, (double)dy) <= (double)vr);
+                    if (visible) {
+                        bool pred = false;
+                        for (int k = 0; k < P; k++) {
+                            int px = py_round(l.def[k]), py = py_round(l.def[P + k]);
+                            if (abs(px - x) <= ext && abs(py - y) <= ext) pred = true;
+                        }
+                        v = pred;
+                    }
+                }
+            }
+            l.obs[i] = v;
+        }
+        wave_sync();
+        int nexp = 0;
+        len = dev_astar(W, H, l, lane, sx, sy, gx, gy, path, c.max_path, &cnt, &nexp, &status);
+        total_exp += nexp;
+        wave_sync();
+        if (len >= 2) break;
+        ext -= 1;
+    }
+    if (lane == 0) {
+        meta[PE_META_PATH_LEN] = len;
+        meta[PE_META_PATH_CNT] = cnt;
+        meta[PE_META_ASTAR_EXP] = total_exp;
+        if (status) meta[PE_META_STATUS] |= status;
+        l.misc[1] = len;
+        l.misc[2] = cnt;
+    }
+    wave_sync();
+}
+
+// ---- Pursuit_Env.attacker_step (pursuit_env.py:75-102), waypoint2phi (agent.py:261-271) -----------------
+template <bool REPLAN>
+__device__ void dev_evader(const pe_config &c, const Lds &l, int lane, int32_t *meta, int16_t *path, int32_t *target,
+                           const int32_t *tape, double *eva_hbm) {
+    const int t = l.misc[0];
+    int len = meta[PE_META_PATH_LEN], cnt = meta[PE_META_PATH_CNT];
+    if (REPLAN) {
+        if (t % c.difficulty == 0) {  // wave-uniform
+            dev_replan(c, l, lane, meta, path, target);
+            len = l.misc[1];
+            cnt = l.misc[2];
+            __threadfence_block();
+        }
+    }
+    if (lane == 0) {
+        const double ex = l.eva[0], ey = l.eva[1];
+        int status = 0;
+        if (cnt < 1) { status |= PE_STATUS_PATH_UNDERFLOW; cnt = 1; }
+        if (len >= 2) {
+            double lx = (double)path[2 * (cnt - 1)], ly = (double)path[2 * (cnt - 1) + 1];
+            if (norm2(ex - lx, ey - ly) < c.resolution) {
+                len--;
+                if (cnt > 1) cnt--; else status |= PE_STATUS_PATH_UNDERFLOW;
+            }
+        }
+        const double wx = (double)path[2 * (cnt - 1)], wy = (double)path[2 * (cnt - 1) + 1];
+        // phi = sign(dy) * arccos(dx / (r + 1e-3)); u = vmax * (cos phi, sin phi).  cos(arccos(q)) == q and
+        // sin(arccos(q)) == sqrt((1-q)(1+q)) are used in place of libm (same form in the CPU oracle); sign(0) == 0
+        // gives phi == 0.
+        double dx = wx - ex, dy = wy - ey;
+        double radius = norm2(dx, dy);
+        double cphi = 1.0, sphi = 0.0;
+        if (!(radius <= 0.01) && dy != 0.0) {
+            double q = dx / (radius + 1e-3);
+            double s = __builtin_sqrt((1.0 - q) * (1.0 + q));
+            cphi = q;
+            sphi = dy > 0.0 ? s : -s;
+        }
+        double ns[4];
+        dynamic(c.eva_tau, c.eva_dt, ex, ey, l.eva[2], l.eva[3], cphi * c.eva_vmax, sphi * c.eva_vmax, ns);
+        int ix = py_round(ns[0]), iy = py_round(ns[1]);
+        if (in_bound_i(c, ix, iy) && l.grid[ix * c.H + iy] == 0) {
+            l.eva[0] = ns[0]; l.eva[1] = ns[1]; l.eva[2] = ns[2]; l.eva[3] = ns[3];
+            eva_hbm[0] = ns[0]; eva_hbm[1] = ns[1]; eva_hbm[2] = ns[2]; eva_hbm[3] = ns[3];
+        }
+        // the target is re-drawn when the PROPOSED position reaches it (pursuit_env.py:98-100); draws come from the tape
+        if (norm2((double)target[0] - ns[0], (double)target[1] - ns[1]) <= c.eva_collision_radius) {
+            int pos = meta[PE_META_TAPE_POS];
+            int k = pos < c.tape_len ? pos : c.tape_len - 1;
+            if (pos >= c.tape_len) status |= PE_STATUS_TAPE_EXHAUSTED;
+            target[0] = tape[2 * k];
+            target[1] = tape[2 * k + 1];
+            meta[PE_META_TAPE_POS] = pos + 1;
+        }
+        meta[PE_META_PATH_LEN] = len;
+        meta[PE_META_PATH_CNT] = cnt;
+        if (status) meta[PE_META_STATUS] |= status;
+    }
+    wave_sync();
+}
+
+template <bool STEP, bool OBS, bool EVA, bool REPLAN>
+__global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state st, const int32_t *actions, const pe_step_out sout,
+                                               const pe_obs_out oout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int env = blockIdx.x, lane = threadIdx.x;
+    if (env >= st.N) return;
+    Lds l;
+    lds_layout(c, OBS, EVA && REPLAN, smem, &l);
+    const int WH = c.W * c.H, P = c.P;
+    copy_in(l.grid, st.grid + (size_t)env * WH, WH, lane);
+    if (OBS) copy_in(l.bidx, st.bidx + (size_t)env * WH, WH * 2, lane);
+    double *def_hbm = st.def + (size_t)env * 4 * P;
+    double *eva_hbm = st.eva + (size_t)env * 4;
+    if (lane < 4 * P) l.def[lane] = def_hbm[lane];
+    if (lane < 4) l.eva[lane] = eva_hbm[lane];
+    int32_t *meta = st.meta + (size_t)env * PE_META_INTS;
+    if (lane == 0) l.misc[0] = meta[PE_META_T];
+    wave_sync();
+    if (STEP) dev_step(c, l, lane, actions + (size_t)env * P, meta, st.rn + (size_t)env * (1 + 2 * P), def_hbm, sout, env);
+    if (OBS) dev_observe(c, l, lane, env, oout, st.n_obs[env]);
+    if (EVA)
+        dev_evader<REPLAN>(c, l, lane, meta, st.path + (size_t)env * c.max_path * 2, st.target + (size_t)env * 2,
+                           st.tape + (size_t)env * c.tape_len * 2, eva_hbm);
+}
+
+// bidx from the obstacle list (pursuit_env.py:21: index == position in np.argwhere order)
+__global__ void k_build_bidx(const pe_config c, const pe_state st, const int32_t *obs_xy) {
+    const int env = blockIdx.x;
+    const int WH = c.W * c.H;
+    int16_t *b = st.bidx + (size_t)env * WH;
+    for (int i = threadIdx.x; i < WH; i += blockDim.x) b[i] = -1;
+    __syncthreads();
+    const int n = st.n_obs[env];
+    for (int k = threadIdx.x; k < n && k < c.O; k += blockDim.x) {
+        int x = obs_xy[((size_t)env * c.O + k) * 2], y = obs_xy[((size_t)env * c.O + k) * 2 + 1];
+        if (x >= 0 && x < c.W && y >= 0 && y < c.H) b[x * c.H + y] = (int16_t)k;
+    }
+    if (threadIdx.x < PE_META_INTS) st.meta[(size_t)env * PE_META_INTS + threadIdx.x] = 0;
+}
+
+// [N][P][4] (get_state order) -> [N][4][P] records
+__global__ void k_def_aos_to_soa(int N, int P, const double *aos, double *soa) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * P * 4) return;
+    int n = i / (4 * P), r = i - n * 4 * P, k = r / P, a = r - k * P;
+    soa[i] = aos[(size_t)n * 4 * P + a * 4 + k];
+}
+
+__global__ __launch_bounds__(WAVE) void k_astar(int W, int H, int n, const uint8_t *obs, const int32_t *sg, int16_t *out_path,
+                                                int32_t *out_len, int max_path) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= n) return;
+    pe_config c;
+    c.W = W; c.H = H; c.P = 2; c.O = 4;
+    Lds l;
+    lds_layout(c, false, true, smem, &l);
+    const int NN = (W + 1) * (H + 1);
+    for (int i = lane; i < NN; i += WAVE) l.obs[i] = obs[(size_t)b * NN + i];
+    wave_sync();
+    int cnt = 0, nexp = 0, status = 0;
+    int len = dev_astar(W, H, l, lane, sg[4 * b], sg[4 * b + 1], sg[4 * b + 2], sg[4 * b + 3], out_path + (size_t)b * max_path * 2,
+                        max_path, &cnt, &nexp, &status);
+    if (lane == 0) { out_len[2 * b] = len; out_len[2 * b + 1] = nexp; }
+}
+
+__global__ void k_diag_norm2(int n, const double *a, const double *b, double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[i] = norm2(a[i], b[i]);
+        out[n + i] = a[i] / b[i];
+        out[2 * n + i] = (double)py_round(a[i]);
+    }
+}
+
+template <bool STEP, bool OBS, bool EVA, bool REPLAN>
+int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
+    size_t lds = lds_layout(*cfg, OBS, EVA && REPLAN, nullptr, nullptr);
+    auto kern = k_tick<STEP, OBS, EVA, REPLAN>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    pe_step_out s0;
+    memset(&s0, 0, sizeof s0);
+    pe_obs_out o0;
+    memset(&o0, 0, sizeof o0);
+    hipLaunchKernelGGL(kern, dim3(st->N), dim3(WAVE), lds, (hipStream_t)stream, *cfg, *st, actions, so ? *so : s0, oo ? *oo : o0);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int pe_config_check(const pe_config *c) {
+    if (!c) return PE_ERR_NULL;
+    if (c->W < 2 || c->H < 2 || c->W > 255 || c->H > 255 || (c->W + 1) * (c->H + 1) >= 65535) return PE_ERR_BAD_CONFIG;
+    if (c->P < 2 || c->P > PE_MAX_P) return PE_ERR_BAD_CONFIG;  // the reference's communicate() needs P >= 2
+    if (c->O < 4 || (c->O & 3) || c->O > 32767) return PE_ERR_BAD_CONFIG;
+    if (c->num_beams < 1 || c->num_beams > PE_MAX_BEAMS || c->lidar_radius < 0) return PE_ERR_BAD_CONFIG;
+    if (c->difficulty < 1 || c->extend_dis < 0 || c->extend_dis > 8 || c->evader_view < 0) return PE_ERR_BAD_CONFIG;
+    if (c->tape_len < 1 || c->max_path < c->difficulty + 2) return PE_ERR_BAD_CONFIG;
+    if (lds_layout(*c, true, true, nullptr, nullptr) > 160 * 1024) return PE_ERR_BAD_CONFIG;
+    return 0;
+}
+
+int64_t pe_tick_lds_bytes(const pe_config *cfg, int32_t with_replan) {
+    return (int64_t)lds_layout(*cfg, true, with_replan != 0, nullptr, nullptr);
+}
+
+int pe_env_load(const pe_config *cfg, const pe_state *st, const pe_host_init *h, void *stream) {
+    if (!cfg || !st || !h) return PE_ERR_NULL;
+    int rc = pe_config_check(cfg);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t N = st->N, WH = (size_t)cfg->W * cfg->H, P = cfg->P;
+    hipError_t e;
+#define PE_TRY(x) do { e = (x); if (e != hipSuccess) return (int)e; } while (0)
+    PE_TRY(hipMemcpyAsync(st->grid, h->grid, N * WH, hipMemcpyHostToDevice, s));
+    PE_TRY(hipMemcpyAsync(st->n_obs, h->n_obs, N * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    PE_TRY(hipMemcpyAsync(st->eva, h->eva, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    PE_TRY(hipMemcpyAsync(st->target, h->target, N * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    PE_TRY(hipMemcpyAsync(st->tape, h->tape, N * cfg->tape_len * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // staging for the two layout-changing uploads lives in the path / rn-free scratch: allocate from the async pool
+    int32_t *d_obs = nullptr;
+    double *d_def = nullptr;
+    PE_TRY(hipMallocAsync((void **)&d_obs, N * cfg->O * 2 * sizeof(int32_t), s));
+    PE_TRY(hipMallocAsync((void **)&d_def, N * P * 4 * sizeof(double), s));
+    PE_TRY(hipMemcpyAsync(d_obs, h->obs_xy, N * cfg->O * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    PE_TRY(hipMemcpyAsync(d_def, h->def, N * P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_build_bidx, dim3(N), dim3(256), 0, s, *cfg, *st, d_obs);
+    int tot = (int)(N * P * 4);
+    hipLaunchKernelGGL(k_def_aos_to_soa, dim3((tot + 255) / 256), dim3(256), 0, s, (int)N, (int)P, d_def, st->def);
+    if (h->reset_rn) PE_TRY(hipMemsetAsync(st->rn, 0, N * (1 + 2 * P) * sizeof(double), s));
+    PE_TRY(hipFreeAsync(d_obs, s));
+    PE_TRY(hipFreeAsync(d_def, s));
+#undef PE_TRY
+    return (int)hipGetLastError();
+}
+
+int pe_env_observe(const pe_config *cfg, const pe_state *st, const pe_obs_out *out, void *stream) {
+    if (!cfg || !st || !out) return PE_ERR_NULL;
+    return launch<false, true, false, false>(cfg, st, nullptr, nullptr, out, stream);
+}
+
+int pe_evader_step(const pe_config *cfg, const pe_state *st, int32_t may_replan, void *stream) {
+    if (!cfg || !st) return PE_ERR_NULL;
+    return may_replan ? launch<false, false, true, true>(cfg, st, nullptr, nullptr, nullptr, stream)
+                      : launch<false, false, true, false>(cfg, st, nullptr, nullptr, nullptr, stream);
+}
+
+int pe_env_step(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *out, void *stream) {
+    if (!cfg || !st || !actions || !out) return PE_ERR_NULL;
+    return launch<true, false, false, false>(cfg, st, actions, out, nullptr, stream);
+}
+
+int pe_env_tick(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *sout, const pe_obs_out *oout,
+                int32_t may_replan, void *stream) {
+    if (!cfg || !st || !actions || !sout || !oout) return PE_ERR_NULL;
+    return may_replan ? launch<true, true, true, true>(cfg, st, actions, sout, oout, stream)
+                      : launch<true, true, true, false>(cfg, st, actions, sout, oout, stream);
+}
+
+int pe_astar_batch(int32_t W, int32_t H, int32_t n, const uint8_t *obs, const int32_t *sg, int16_t *out_path, int32_t *out_len,
+                   int32_t max_path, void *stream) {
+    pe_config c;
+    memset(&c, 0, sizeof c);
+    c.W = W; c.H = H; c.P = 2; c.O = 4;
+    size_t lds = lds_layout(c, false, true, nullptr, nullptr);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_astar, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_astar, dim3(n), dim3(WAVE), lds, (hipStream_t)stream, W, H, n, obs, sg, out_path, out_len, max_path);
+    return (int)hipGetLastError();
+}
+
+// diagnostic: device f64 norm / divide / round against the host (tests only)
+int pe_diag_norm2(int32_t n, const double *a, const double *b, double *out, void *stream) {
+    hipLaunchKernelGGL(k_diag_norm2, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, a, b, out);
+    return (int)hipGetLastError();
+}
+
+const char *pe_error_string(int code) {
+    if (code == PE_ERR_BAD_CONFIG) return "pe_env: configuration outside kernel limits";
+    if (code == PE_ERR_NULL) return "pe_env: null argument";
+    return hipGetErrorString((hipError_t)code);
+}
+
+}  // extern "C"

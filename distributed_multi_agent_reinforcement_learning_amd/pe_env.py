@@ -1,0 +1,284 @@
+"""ctypes binding of libpe_env.so (include/pe_env.h) plus the device-resident batched environment.
+
+PyTorch is used for device memory and streams only; the simulation runs in the HIP kernels of csrc/pe_env.hip.
+There is no CPU path: importing works anywhere, but constructing a `BatchedEnv` without the built library or a
+GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import build as _build
+from . import tables
+
+MAX_BEAMS = 64
+META_INTS = 8
+META_T, META_PATH_LEN, META_TAPE_POS, META_COLLISION, META_PATH_CNT, META_ASTAR_EXP, META_STATUS = range(7)
+
+
+class PeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("W", "H", "P", "O", "max_steps", "difficulty", "extend_dis", "num_beams",
+                                          "lidar_radius", "evader_view", "tape_len", "max_path", "use_reward_norm",
+                                          "pad0")] + \
+               [(n, C.c_double) for n in ("def_tau", "def_dt", "def_collision_radius", "def_comm_range", "def_sen_range",
+                                          "eva_vmax", "eva_tau", "eva_dt", "eva_collision_radius", "resolution")] + \
+               [("action_u", (C.c_double * 2) * 9), ("beam_dir", (C.c_double * 2) * MAX_BEAMS)]
+
+
+class PeState(C.Structure):
+    _fields_ = [("N", C.c_int32), ("pad0", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("grid", "bidx", "n_obs", "def_", "eva", "target", "tape", "meta", "path", "rn")]
+
+
+class PeObsOut(C.Structure):
+    _fields_ = [("p_state", C.c_void_p), ("p_state_stride", C.c_int64), ("e_state", C.c_void_p), ("e_state_stride", C.c_int64),
+                ("p_adj", C.c_void_p), ("p_adj_stride", C.c_int64), ("e_adj", C.c_void_p), ("e_adj_stride", C.c_int64),
+                ("o_adj", C.c_void_p), ("o_adj_stride", C.c_int64)]
+
+
+class PeStepOut(C.Structure):
+    _fields_ = [("reward", C.c_void_p), ("reward_stride", C.c_int64), ("reward_raw", C.c_void_p),
+                ("reward_raw_stride", C.c_int64), ("done", C.c_void_p)]
+
+
+class PeHostInit(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("grid", "obs_xy", "n_obs", "def_", "eva", "target", "tape")] + \
+               [("reset_rn", C.c_int32), ("pad0", C.c_int32)]
+
+
+EXPORTS = ("pe_config_check", "pe_tick_lds_bytes", "pe_env_load", "pe_env_observe", "pe_evader_step", "pe_env_step",
+           "pe_env_tick", "pe_astar_batch", "pe_error_string")
+
+_lib = None
+
+
+def lib_path():
+    return _build.lib_path("libpe_env.so")
+
+
+def load_library():
+    """Loads libpe_env.so; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); the environment has no CPU fallback")
+        L = C.CDLL(path)
+        vp = C.c_void_p
+        L.pe_config_check.argtypes = [vp]
+        L.pe_tick_lds_bytes.argtypes = [vp, C.c_int32]
+        L.pe_tick_lds_bytes.restype = C.c_int64
+        L.pe_env_load.argtypes = [vp, vp, vp, vp]
+        L.pe_env_observe.argtypes = [vp, vp, vp, vp]
+        L.pe_evader_step.argtypes = [vp, vp, C.c_int32, vp]
+        L.pe_env_step.argtypes = [vp, vp, vp, vp, vp]
+        L.pe_env_tick.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
+        L.pe_astar_batch.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]
+        L.pe_diag_norm2.argtypes = [C.c_int32, vp, vp, vp, vp]
+        L.pe_error_string.argtypes = [C.c_int]
+        L.pe_error_string.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {load_library().pe_error_string(rc).decode()} (code {rc})")
+
+
+def make_pe_config(cfg, tape_len=16, max_path=128):
+    """Reference config sections (config.yaml:13-54) -> pe_config."""
+    c = PeConfig()
+    c.W, c.H = int(cfg.map.map_size[0]), int(cfg.map.map_size[1])
+    c.P = int(cfg.env.num_defender)
+    c.O = int(cfg.map.num_max_obstacle)
+    c.max_steps = int(cfg.env.max_steps)
+    c.difficulty = int(cfg.env.difficulty)
+    c.extend_dis = int(cfg.attacker.extend_dis)
+    c.num_beams = int(cfg.sensor.num_beams)
+    c.lidar_radius = int(cfg.sensor.radius)
+    c.evader_view = int(cfg.attacker.sen_range)
+    c.tape_len = int(tape_len)
+    c.max_path = int(max(max_path, c.difficulty + 2))
+    c.use_reward_norm = 1 if cfg.algo.use_reward_norm else 0
+    c.def_tau, c.def_dt = float(cfg.defender.tau), float(cfg.defender.step_size)
+    c.def_collision_radius = float(cfg.defender.collision_radius)
+    c.def_comm_range, c.def_sen_range = float(cfg.defender.comm_range), float(cfg.defender.sen_range)
+    c.eva_vmax, c.eva_tau, c.eva_dt = float(cfg.attacker.vmax), float(cfg.attacker.tau), float(cfg.attacker.step_size)
+    c.eva_collision_radius = float(cfg.attacker.collision_radius)
+    c.resolution = float(cfg.map.resolution)
+    for k, (ux, uy) in enumerate(tables.action_table(float(cfg.defender.vmax))):
+        c.action_u[k][0], c.action_u[k][1] = ux, uy
+    for b, (bx, by) in enumerate(tables.beam_table(c.num_beams)):
+        c.beam_dir[b][0], c.beam_dir[b][1] = bx, by
+    return c
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _np(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BatchedEnv:
+    """N independent pursuit-evasion environments resident in HBM, stepped by the HIP kernels.
+
+    The tensor attributes are the `pe_state` records of include/pe_env.h; `obs` holds the fp32 observation tensors in
+    the reference's layouts (N leading)."""
+
+    def __init__(self, pe_cfg: PeConfig, num_envs: int, device="cuda"):
+        self.L = load_library()
+        _check(self.L.pe_config_check(C.byref(pe_cfg)), "pe_config_check")
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedEnv needs a GPU (MI355X); there is no CPU path")
+        self.c = pe_cfg
+        self.N = int(num_envs)
+        self.device = torch.device(device)
+        c, N, dev = pe_cfg, self.N, self.device
+        WH, P = c.W * c.H, c.P
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.grid = z((N, WH), torch.uint8)
+        self.bidx = z((N, WH), torch.int16)
+        self.n_obs = z((N,), torch.int32)
+        self.defs = z((N, 4, P), torch.float64)
+        self.eva = z((N, 4), torch.float64)
+        self.target = z((N, 2), torch.int32)
+        self.tape = z((N, c.tape_len, 2), torch.int32)
+        self.meta = z((N, META_INTS), torch.int32)
+        self.path = z((N, c.max_path, 2), torch.int16)
+        self.rn = z((N, 1 + 2 * P), torch.float64)
+        self.o_state = z((N, c.O, 4), torch.float32)  # boundary obstacles as [x, y, 0, 0] (pursuit_env.py:22-26), padded
+        self.st = PeState()
+        self.st.N = N
+        for name, t in (("grid", self.grid), ("bidx", self.bidx), ("n_obs", self.n_obs), ("def_", self.defs), ("eva", self.eva),
+                        ("target", self.target), ("tape", self.tape), ("meta", self.meta), ("path", self.path), ("rn", self.rn)):
+            setattr(self.st, name, t.data_ptr())
+        self.t_host = None  # lockstep time_step known to the host (None: unknown -> always allow replans)
+
+    # -- hand-over of Pursuit_Env.reset() results --------------------------------------------------------
+    def load(self, init, reset_reward_norm=False):
+        """init: dict of host numpy arrays grid [N,W,H] u8, obs_xy [N,O,2] i32 (padded), n_obs [N], defenders [N,P,4] f64,
+        evader [N,4] f64, target [N,2] i32, tape [N,tape_len,2] i32."""
+        c, N = self.c, self.N
+        g = np.ascontiguousarray(init["grid"], np.uint8).reshape(N, c.W * c.H)
+        ob = np.ascontiguousarray(init["obs_xy"], np.int32).reshape(N, c.O, 2)
+        no = np.ascontiguousarray(init["n_obs"], np.int32).reshape(N)
+        if int(no.max()) > c.O:
+            raise ValueError(f"an environment has {int(no.max())} boundary obstacles > num_max_obstacle={c.O}")
+        d = np.ascontiguousarray(init["defenders"], np.float64).reshape(N, c.P, 4)
+        e = np.ascontiguousarray(init["evader"], np.float64).reshape(N, 4)
+        tg = np.ascontiguousarray(init["target"], np.int32).reshape(N, 2)
+        tp = np.ascontiguousarray(init["tape"], np.int32).reshape(N, c.tape_len, 2)
+        h = PeHostInit()
+        h.grid, h.obs_xy, h.n_obs, h.def_, h.eva, h.target, h.tape = (_np(g), _np(ob), _np(no), _np(d), _np(e), _np(tg), _np(tp))
+        h.reset_rn = 1 if reset_reward_norm else 0
+        self._keep = (g, ob, no, d, e, tg, tp)  # the async copies read these host arrays
+        with torch.cuda.device(self.device):
+            _check(self.L.pe_env_load(C.byref(self.c), C.byref(self.st), C.byref(h), _stream()), "pe_env_load")
+            torch.cuda.current_stream().synchronize()
+        self._keep = None
+        os_ = np.zeros((N, c.O, 4), np.float32)
+        os_[:, :, :2] = ob.astype(np.float32)
+        valid = np.arange(c.O)[None, :] < no[:, None]
+        os_[~valid] = 0.0
+        self.o_state.copy_(torch.from_numpy(os_))
+        self.t_host = 0
+
+    # -- observation / step entry points -----------------------------------------------------------------
+    def new_obs(self):
+        c, N, dev = self.c, self.N, self.device
+        f = lambda *s: torch.empty((N, *s), dtype=torch.float32, device=dev)
+        return dict(p_state=f(c.P, 4), e_state=f(1, 4), p_adj=f(c.P, c.P), e_adj=f(c.P, 1), o_adj=f(c.P, c.O))
+
+    @staticmethod
+    def _obs_struct(obs):
+        o = PeObsOut()
+        for k in ("p_state", "e_state", "p_adj", "e_adj", "o_adj"):
+            t = obs.get(k) if obs else None
+            if t is not None:
+                assert t.dtype == torch.float32 and t[0].is_contiguous(), k
+                setattr(o, k, t.data_ptr())
+                setattr(o, k + "_stride", t.stride(0))
+        return o
+
+    @staticmethod
+    def _step_struct(reward, reward_raw, done):
+        s = PeStepOut()
+        if reward is not None:
+            assert reward.dtype == torch.float32 and reward[0].is_contiguous()
+            s.reward, s.reward_stride = reward.data_ptr(), reward.stride(0)
+        if reward_raw is not None:
+            assert reward_raw.dtype == torch.float32 and reward_raw[0].is_contiguous()
+            s.reward_raw, s.reward_raw_stride = reward_raw.data_ptr(), reward_raw.stride(0)
+        if done is not None:
+            assert done.dtype == torch.uint8 and done.is_contiguous()
+            s.done = done.data_ptr()
+        return s
+
+    def _may_replan(self):
+        return 1 if (self.t_host is None or self.t_host % self.c.difficulty == 0) else 0
+
+    def observe(self, obs=None):
+        obs = obs if obs is not None else self.new_obs()
+        o = self._obs_struct(obs)
+        _check(self.L.pe_env_observe(C.byref(self.c), C.byref(self.st), C.byref(o), _stream()), "pe_env_observe")
+        return obs
+
+    def evader_step(self):
+        _check(self.L.pe_evader_step(C.byref(self.c), C.byref(self.st), self._may_replan(), _stream()), "pe_evader_step")
+
+    def step(self, actions, reward=None, reward_raw=None, done=None):
+        a = self._actions(actions)
+        if reward is None:
+            reward = torch.empty((self.N, self.c.P), dtype=torch.float32, device=self.device)
+        s = self._step_struct(reward, reward_raw, done)
+        _check(self.L.pe_env_step(C.byref(self.c), C.byref(self.st), _ptr(a), C.byref(s), _stream()), "pe_env_step")
+        if self.t_host is not None:
+            self.t_host += 1
+        return reward
+
+    def tick(self, actions, obs, reward, reward_raw=None, done=None):
+        """Fused step(actions) -> observe -> attacker_step (one launch)."""
+        a = self._actions(actions)
+        s = self._step_struct(reward, reward_raw, done)
+        o = self._obs_struct(obs)
+        if self.t_host is not None:
+            self.t_host += 1
+        _check(self.L.pe_env_tick(C.byref(self.c), C.byref(self.st), _ptr(a), C.byref(s), C.byref(o), self._may_replan(),
+                                  _stream()), "pe_env_tick")
+
+    def _actions(self, actions):
+        if actions.dtype != torch.int32:
+            actions = actions.to(torch.int32)
+        actions = actions.contiguous()
+        assert actions.shape == (self.N, self.c.P) and actions.device.type == "cuda"
+        return actions
+
+    # -- host read-back (tests, logging) ---------------------------------------------------------------------
+    def defenders_aos(self):
+        return self.defs.permute(0, 2, 1).contiguous()  # [N][P][4] like get_state('defender')
+
+    def status(self):
+        return self.meta[:, META_STATUS]
+
+
+def astar_batch(W, H, obs, sg, max_path=256):
+    """Diagnostic/test entry: one weighted-A* problem per workgroup. obs [n,(W+1),(H+1)] u8, sg [n,4] int."""
+    L = load_library()
+    n = obs.shape[0]
+    obs_d = torch.as_tensor(np.ascontiguousarray(obs, np.uint8)).cuda()
+    sg_d = torch.as_tensor(np.ascontiguousarray(sg, np.int32)).cuda()
+    path = torch.zeros((n, max_path, 2), dtype=torch.int16, device="cuda")
+    lens = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+    _check(L.pe_astar_batch(W, H, n, _ptr(obs_d), _ptr(sg_d), _ptr(path), _ptr(lens), max_path, _stream()), "pe_astar_batch")
+    torch.cuda.synchronize()
+    return path.cpu().numpy(), lens.cpu().numpy()

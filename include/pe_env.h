@@ -1,0 +1,140 @@
+/*
+ * pe_env.h -- C ABI of the MI355X (gfx950) batched pursuit-evasion environment.
+ *
+ * Drop-in boundary for the reference's environment object on the MAPPO hot path.  The reference has no
+ * native FFI: the seam is the Python class `Pursuit_Env` (environment/pursuit_evasion_game/pursuit_env.py:56)
+ * called by `MAPPO.run_episode` (DHGN/mappo_parallel.py:742-827) and `evaluate` (evaluator.py:106-201).  Each
+ * entry point below replaces the method(s) cited next to it for N independent environments at once; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: every pointer in pe_state / pe_obs_out / pe_step_out is a DEVICE pointer owned by the caller
+ * (e.g. a torch tensor); kernels are enqueued on the caller's stream (a hipStream_t passed as void*); functions
+ * return 0 on success or a non-zero hipError_t / PE_ERR_* code, never throw, and keep no hidden state.
+ * One 64-lane wavefront steps one environment; the environment's record is contiguous in HBM.
+ */
+#ifndef PE_ENV_H
+#define PE_ENV_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PE_MAX_BEAMS 64
+#define PE_MAX_P 16          /* defenders per environment */
+#define PE_META_INTS 8
+#define PE_ERR_BAD_CONFIG 10001
+#define PE_ERR_NULL 10002
+
+/* meta[env][k] */
+enum { PE_META_T = 0, PE_META_PATH_LEN = 1, PE_META_TAPE_POS = 2, PE_META_COLLISION = 3, PE_META_PATH_CNT = 4,
+       PE_META_ASTAR_EXP = 5, PE_META_STATUS = 6, PE_META_PAD = 7 };
+/* meta[PE_META_STATUS] bits */
+enum { PE_STATUS_TAPE_EXHAUSTED = 1, PE_STATUS_ASTAR_CAP = 2, PE_STATUS_PATH_UNDERFLOW = 4 };
+
+/* Values of config.yaml (reference config.yaml:13-54) the kernels need.  Plain data, passed by value. */
+typedef struct pe_config {
+    int32_t W, H;             /* map.map_size */
+    int32_t P;                /* env.num_defender (2..PE_MAX_P) */
+    int32_t O;                /* map.num_max_obstacle: padded obstacle slots of o_adj (multiple of 4) */
+    int32_t max_steps;        /* env.max_steps */
+    int32_t difficulty;       /* env.difficulty: evader replans when time_step % difficulty == 0 */
+    int32_t extend_dis;       /* attacker.extend_dis */
+    int32_t num_beams;        /* sensor.num_beams (<= PE_MAX_BEAMS) */
+    int32_t lidar_radius;     /* sensor.radius */
+    int32_t evader_view;      /* attacker.sen_range */
+    int32_t tape_len;         /* pre-drawn evader targets per environment and episode */
+    int32_t max_path;         /* stored tail of the evader path (>= difficulty + 2) */
+    int32_t use_reward_norm;  /* algo.use_reward_norm */
+    int32_t pad0;
+    double def_tau, def_dt, def_collision_radius, def_comm_range, def_sen_range;
+    double eva_vmax, eva_tau, eva_dt, eva_collision_radius;
+    double resolution;
+    double action_u[9][2];    /* desired velocity per discrete action (agent.py:57-60), already times vmax */
+    double beam_dir[PE_MAX_BEAMS][2]; /* LiDAR beam directions (pursuit_env.py:37-39) */
+} pe_config;
+
+/* Environment state in HBM.  [N] leading dimension everywhere; records are contiguous per environment. */
+typedef struct pe_state {
+    int32_t N;
+    int32_t pad0;
+    uint8_t *grid;      /* [N][W*H]      static occupancy, cell (x,y) at x*H+y (Occupied_Grid_Map.py:16)      */
+    int16_t *bidx;      /* [N][W*H]      index of the boundary obstacle in that cell, or -1 (pursuit_env.py:18-27) */
+    int32_t *n_obs;     /* [N]                                                                                  */
+    double *def;        /* [N][4][P]     x[P], y[P], vx[P], vy[P]: struct-of-arrays over agents inside the record */
+    double *eva;        /* [N][4]        x, y, vx, vy of the evader                                              */
+    int32_t *target;    /* [N][2]                                                                                */
+    int32_t *tape;      /* [N][tape_len][2]  targets the evader is assigned after reaching the current one      */
+    int32_t *meta;      /* [N][PE_META_INTS]                                                                     */
+    int16_t *path;      /* [N][max_path][2]  tail of the A* path; path[cnt-1] is the next waypoint               */
+    double *rn;         /* [N][1+2P]     reward normaliser: n, mean[P], S[P] (DHGN/normalization.py:4-22)        */
+} pe_state;
+
+/* Observations, fp32, reference layouts (DHGN/mappo_parallel.py:767-771, replay_buffer.py:28-33).  Every tensor
+ * has its own per-environment element stride so the kernel can write straight into replay-buffer slices
+ * buffer[key][:, t].  A NULL pointer skips that output. */
+typedef struct pe_obs_out {
+    float *p_state; int64_t p_state_stride;  /* [N][P][4]  */
+    float *e_state; int64_t e_state_stride;  /* [N][1][4]  */
+    float *p_adj;   int64_t p_adj_stride;    /* [N][P][P]  communicate() incl. its column-1 quirk */
+    float *e_adj;   int64_t e_adj_stride;    /* [N][P][1]  find_attacker()                        */
+    float *o_adj;   int64_t o_adj_stride;    /* [N][P][O]  LiDAR row, zero padded to O            */
+} pe_obs_out;
+
+typedef struct pe_step_out {
+    float *reward;     int64_t reward_stride;      /* [N][P] normalised reward (or raw if !use_reward_norm), fp32 */
+    float *reward_raw; int64_t reward_raw_stride;  /* [N][P] raw reward (pursuit_env.py:128-149), may be NULL      */
+    uint8_t *done;                                 /* [N]    time_step >= max_steps, may be NULL                   */
+} pe_step_out;
+
+/* Host-side initial condition of every environment (what Pursuit_Env.reset produces, pursuit_env.py:60-73).
+ * HOST pointers; pe_env_load copies them to the device and derives bidx.  rn is left untouched (the reward
+ * normaliser persists across episodes, DHGN/mappo_parallel.py:579-580) unless reset_rn != 0. */
+typedef struct pe_host_init {
+    const uint8_t *grid;      /* [N][W*H]          */
+    const int32_t *obs_xy;    /* [N][O][2]  boundary obstacles in index order, first n_obs[n] valid */
+    const int32_t *n_obs;     /* [N]               */
+    const double *def;        /* [N][P][4]  x,y,vx,vy (array-of-structs, as get_state returns it)   */
+    const double *eva;        /* [N][4]            */
+    const int32_t *target;    /* [N][2]            */
+    const int32_t *tape;      /* [N][tape_len][2]  */
+    int32_t reset_rn;
+    int32_t pad0;
+} pe_host_init;
+
+/* Validates a configuration against the kernels' limits. */
+int pe_config_check(const pe_config *cfg);
+/* Bytes of dynamic LDS one workgroup of the fused tick uses (for occupancy reports). */
+int64_t pe_tick_lds_bytes(const pe_config *cfg, int32_t with_replan);
+
+/* Pursuit_Env.reset() hand-over: host initial conditions -> device records (pursuit_env.py:60-73). */
+int pe_env_load(const pe_config *cfg, const pe_state *st, const pe_host_init *init, void *stream);
+
+/* get_state + communicate + sensor (base_env.py:198-209, pursuit_env.py:182-209, agent.py:157-169, 319-341),
+ * LiDAR evaluated on the fly instead of through the per-reset raser map (pursuit_env.py:29-53). */
+int pe_env_observe(const pe_config *cfg, const pe_state *st, const pe_obs_out *out, void *stream);
+
+/* Pursuit_Env.attacker_step (pursuit_env.py:75-102) incl. Evader.replan / rescan / A* (agent.py:202-271,
+ * astar.py:26-161).  may_replan == 0 promises that no environment has time_step % difficulty == 0. */
+int pe_evader_step(const pe_config *cfg, const pe_state *st, int32_t may_replan, void *stream);
+
+/* Pursuit_Env.step (pursuit_env.py:104-149) + reward normalisation (DHGN/normalization.py:29-35). */
+int pe_env_step(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *out, void *stream);
+
+/* Fused rollout tick: step(actions) -> observe -> attacker_step in ONE launch (the order of
+ * DHGN/mappo_parallel.py:793 followed by :759-765 of the next loop iteration). */
+int pe_env_tick(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *sout,
+                const pe_obs_out *oout, int32_t may_replan, void *stream);
+
+/* Weighted A* of the evader on one standalone problem per workgroup (astar.py:26-161); test/diagnostic entry.
+ * obs: [n][(W+1)*(H+1)] device bytes, sg: [n][4] (sx,sy,gx,gy), out_path: [n][max_path][2], out_len: [n][2]
+ * (true length, expansions). */
+int pe_astar_batch(int32_t W, int32_t H, int32_t n, const uint8_t *obs, const int32_t *sg, int16_t *out_path,
+                   int32_t *out_len, int32_t max_path, void *stream);
+
+const char *pe_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -386,3 +386,8 @@ double peo_tick_batch(const peo_config *c, peo_env **envs, int n, const int32_t 
     }
     return acc;
 }
+
+/* elementwise primitives for device-vs-host checks (tests only) */
+void peo_prims(int n, const double *a, const double *b, double *out) {
+    for (int i = 0; i < n; i++) { out[i] = norm2(a[i], b[i]); out[n + i] = a[i] / b[i]; out[2 * n + i] = (double)py_round(a[i]); }
+}

@@ -96,6 +96,8 @@ void peo_get_rn(const peo_config *c, const peo_env *e, double *n_mean_S /* [1+2P
  * with the given actions [n*P]; returns a checksum so the work cannot be optimised away. */
 double peo_tick_batch(const peo_config *c, peo_env **envs, int n, const int32_t *actions, float *scratch);
 
+void peo_prims(int n, const double *a, const double *b, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,7 @@ def lib():
         L.peo_astar.restype = C.c_int
         L.peo_tick_batch.argtypes = [vp, vp, C.c_int, vp, vp]
         L.peo_tick_batch.restype = C.c_double
+        L.peo_prims.argtypes = [C.c_int, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -179,3 +180,10 @@ def tick_batch(cfg, envs, actions):
     a = np.ascontiguousarray(actions, np.int32)
     scratch = np.zeros(4 * cfg.P + 4 + cfg.P * cfg.P + cfg.P + cfg.P * cfg.O, np.float32)
     return lib().peo_tick_batch(C.byref(cfg), hs, n, _p(a), _p(scratch))
+
+
+def prims(a, b):
+    a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64)
+    out = np.zeros((3, len(a)))
+    lib().peo_prims(len(a), _p(a), _p(b), _p(out))
+    return out

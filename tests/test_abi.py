@@ -1,0 +1,53 @@
+"""CPU-side checks of the C-ABI boundary: the libraries build, load and export every symbol the headers declare."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests.conftest import ROOT
+
+
+def declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b([a-z][a-z0-9_]*)\s*\([^;{}]*\)\s*;", txt)))
+
+
+@pytest.mark.parametrize("header,libname", [("pe_env.h", "libpe_env.so")])
+def test_library_exports_every_declared_symbol(header, libname):
+    from distributed_multi_agent_reinforcement_learning_amd import build
+    path = build.build_lib(libname)
+    assert path and os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    names = declared_functions(header)
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"{libname} does not export {n} declared in include/{header}"
+
+
+def test_config_check_rejects_out_of_range():
+    from distributed_multi_agent_reinforcement_learning_amd import pe_env
+    from tests.helpers import product_cfg
+    L = pe_env.load_library()
+    ok = pe_env.make_pe_config(product_cfg(8, 40, 40))
+    assert L.pe_config_check(ctypes.byref(ok)) == 0
+    bad = pe_env.make_pe_config(product_cfg(8, 40, 40)); bad.P = 1
+    assert L.pe_config_check(ctypes.byref(bad)) != 0
+    bad = pe_env.make_pe_config(product_cfg(8, 40, 40)); bad.max_path = 3
+    assert L.pe_config_check(ctypes.byref(bad)) != 0
+    assert 0 < L.pe_tick_lds_bytes(ctypes.byref(ok), 0) < L.pe_tick_lds_bytes(ctypes.byref(ok), 1) <= 160 * 1024
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors of pe_config / pe_state must have the C layout (checked against a tiny C program)."""
+    import subprocess, tempfile
+    from distributed_multi_agent_reinforcement_learning_amd import pe_env
+    src = '#include <stdio.h>\n#include "pe_env.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(pe_config), sizeof(pe_state), sizeof(pe_obs_out), sizeof(pe_step_out), sizeof(pe_host_init));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), os.path.join(td, "s.c"), "-o", os.path.join(td, "s")])
+        out = subprocess.check_output([os.path.join(td, "s")]).decode().split()
+    sizes = [int(v) for v in out]
+    mine = [ctypes.sizeof(t) for t in (pe_env.PeConfig, pe_env.PeState, pe_env.PeObsOut, pe_env.PeStepOut, pe_env.PeHostInit)]
+    assert sizes == mine, (sizes, mine)
