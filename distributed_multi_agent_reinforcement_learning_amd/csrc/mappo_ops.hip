@@ -1,0 +1,332 @@
+// mappo_ops.hip -- fused fp32 ops of the MAPPO rollout/update path for MI355X (gfx950).  C ABI: include/mappo_ops.h.
+//
+// dhgn_msg_agg_{fwd,bwd}: the relation message ReLU(W (p_i - q_j) + b) and its adjacency-weighted mean are fused so
+// the (rows, P, K, E) message tensor (865 MB per reference mini-batch) never exists; backward recomputes the
+// pre-activation.  One workgroup of E lanes (E/64 wavefronts) walks rows; lane = output feature, so the adjacency
+// test is wave-uniform (sparse LiDAR rows skip ~80 % of the neighbours) and p/q/adj are LDS broadcasts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mappo_ops.h"
+
+namespace {
+
+constexpr int MAX_P = 16;
+
+struct MsgArgs {
+    int R, P, K, E, din, q_div, adj_mode;
+    const float *p, *q, *e, *adj;
+    const int32_t *kvalid;
+    const float *W, *b;
+};
+
+// stages one row (p, q, adjacency) in LDS; returns the 1/L1-norm per agent in s_inv[P]
+__device__ __forceinline__ void stage_row(const MsgArgs &a, int r, float *s_p, float *s_q, float *s_adj, float *s_inv, float *s_pe,
+                                          int tid, int nthr) {
+    const int P = a.P, K = a.K;
+    const int qr = r / a.q_div;
+    for (int i = tid; i < P * 4; i += nthr) s_p[i] = a.p[(size_t)r * P * 4 + i];
+    {
+        const float4 *src = (const float4 *)(a.q + (size_t)qr * K * 4);
+        float4 *dst = (float4 *)s_q;
+        for (int i = tid; i < K; i += nthr) dst[i] = src[i];
+    }
+    if (a.adj_mode == MO_ADJ_TENSOR) {
+        const float *src = a.adj + (size_t)r * P * K;
+        if (((P * K) & 3) == 0) {
+            for (int i = tid; i < (P * K) >> 2; i += nthr) ((float4 *)s_adj)[i] = ((const float4 *)src)[i];
+        } else {
+            for (int i = tid; i < P * K; i += nthr) s_adj[i] = src[i];
+        }
+    }
+    __syncthreads();
+    if (tid < P) {
+        float s = 0.f;
+        if (a.adj_mode == MO_ADJ_TENSOR) {
+            for (int j = 0; j < K; j++) s += fabsf(s_adj[tid * K + j]);
+        } else if (a.adj_mode == MO_ADJ_ONES) {
+            s = (float)K;
+        } else {
+            s = (float)a.kvalid[qr];
+        }
+        s_inv[tid] = 1.f / fmaxf(s, 1e-12f);
+        if (a.din == 8) {
+            for (int k = 0; k < 4; k++) s_pe[tid * 4 + k] = s_p[tid * 4 + k] - a.e[(size_t)r * 4 + k];
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void k_msg_agg_fwd(MsgArgs a, float *out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = a.P, K = a.K, E = a.E;
+    float *s_q = smem;                  // [K][4]
+    float *s_adj = s_q + K * 4;         // [P][K]
+    float *s_p = s_adj + ((P * K + 3) & ~3);  // [P][4]
+    float *s_pe = s_p + P * 4;          // [P][4]
+    float *s_inv = s_pe + P * 4;        // [P]
+    const int tid = threadIdx.x, f = tid;  // lane == feature
+    float w[8];
+    for (int k = 0; k < a.din; k++) w[k] = a.W[(size_t)f * a.din + k];
+    const float bias = a.b[f];
+    for (int r = blockIdx.x; r < a.R; r += gridDim.x) {
+        stage_row(a, r, s_p, s_q, s_adj, s_inv, s_pe, tid, blockDim.x);
+        int kv = K;
+        if (a.adj_mode == MO_ADJ_VALID) kv = a.kvalid[r / a.q_div];
+        for (int i = 0; i < P; i++) {
+            const float px = s_p[i * 4], py = s_p[i * 4 + 1], pvx = s_p[i * 4 + 2], pvy = s_p[i * 4 + 3];
+            float c = bias;
+            if (a.din == 8) c += w[4] * s_pe[i * 4] + w[5] * s_pe[i * 4 + 1] + w[6] * s_pe[i * 4 + 2] + w[7] * s_pe[i * 4 + 3];
+            const float inv = s_inv[i];
+            float acc = 0.f;
+            if (a.adj_mode == MO_ADJ_TENSOR) {
+                for (int j = 0; j < K; j++) {
+                    const float aij = s_adj[i * K + j];
+                    if (aij != 0.f) {  // wave-uniform
+                        const float4 qv = ((const float4 *)s_q)[j];
+                        float z = c + w[0] * (px - qv.x) + w[1] * (py - qv.y) + w[2] * (pvx - qv.z) + w[3] * (pvy - qv.w);
+                        acc += (aij * inv) * fmaxf(z, 0.f);
+                    }
+                }
+            } else {
+                for (int j = 0; j < kv; j++) {
+                    const float4 qv = ((const float4 *)s_q)[j];
+                    float z = c + w[0] * (px - qv.x) + w[1] * (py - qv.y) + w[2] * (pvx - qv.z) + w[3] * (pvy - qv.w);
+                    acc += inv * fmaxf(z, 0.f);
+                }
+            }
+            out[((size_t)r * P + i) * E + f] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// partials: [gridDim.x][din + 1][E]
+__global__ void k_msg_agg_bwd(MsgArgs a, const float *gout, float *partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = a.P, K = a.K, E = a.E;
+    float *s_q = smem;
+    float *s_adj = s_q + K * 4;
+    float *s_p = s_adj + ((P * K + 3) & ~3);
+    float *s_pe = s_p + P * 4;
+    float *s_inv = s_pe + P * 4;
+    const int tid = threadIdx.x, f = tid;
+    float w[8], gw[8];
+    for (int k = 0; k < 8; k++) { w[k] = 0.f; gw[k] = 0.f; }
+    for (int k = 0; k < a.din; k++) w[k] = a.W[(size_t)f * a.din + k];
+    const float bias = a.b[f];
+    float gb = 0.f;
+    for (int r = blockIdx.x; r < a.R; r += gridDim.x) {
+        stage_row(a, r, s_p, s_q, s_adj, s_inv, s_pe, tid, blockDim.x);
+        int kv = K;
+        if (a.adj_mode == MO_ADJ_VALID) kv = a.kvalid[r / a.q_div];
+        for (int i = 0; i < P; i++) {
+            const float px = s_p[i * 4], py = s_p[i * 4 + 1], pvx = s_p[i * 4 + 2], pvy = s_p[i * 4 + 3];
+            float c = bias;
+            if (a.din == 8) c += w[4] * s_pe[i * 4] + w[5] * s_pe[i * 4 + 1] + w[6] * s_pe[i * 4 + 2] + w[7] * s_pe[i * 4 + 3];
+            const float gi = gout[((size_t)r * P + i) * E + f] * s_inv[i];
+            float gsum = 0.f;
+            const int jn = (a.adj_mode == MO_ADJ_TENSOR) ? K : kv;
+            for (int j = 0; j < jn; j++) {
+                float aij = 1.f;
+                if (a.adj_mode == MO_ADJ_TENSOR) {
+                    aij = s_adj[i * K + j];
+                    if (aij == 0.f) continue;  // wave-uniform
+                }
+                const float4 qv = ((const float4 *)s_q)[j];
+                const float d0 = px - qv.x, d1 = py - qv.y, d2 = pvx - qv.z, d3 = pvy - qv.w;
+                const float z = c + w[0] * d0 + w[1] * d1 + w[2] * d2 + w[3] * d3;
+                const float g = z > 0.f ? gi * aij : 0.f;
+                gw[0] += g * d0; gw[1] += g * d1; gw[2] += g * d2; gw[3] += g * d3;
+                gsum += g;
+            }
+            gb += gsum;
+            if (a.din == 8) {
+                gw[4] += gsum * s_pe[i * 4]; gw[5] += gsum * s_pe[i * 4 + 1];
+                gw[6] += gsum * s_pe[i * 4 + 2]; gw[7] += gsum * s_pe[i * 4 + 3];
+            }
+        }
+        __syncthreads();
+    }
+    float *dst = partials + (size_t)blockIdx.x * (a.din + 1) * E;
+    for (int k = 0; k < a.din; k++) dst[k * E + f] = gw[k];
+    dst[a.din * E + f] = gb;
+}
+
+__global__ void k_msg_agg_bwd_reduce(int nblk, int E, int din, const float *partials, float *dW, float *db) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (din+1)*E
+    if (idx >= (din + 1) * E) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; b++) s += (double)partials[(size_t)b * (din + 1) * E + idx];
+    const int k = idx / E, f = idx - k * E;
+    if (k < din) dW[(size_t)f * din + k] = (float)s; else db[f] = (float)s;
+}
+
+// ---- GAE ---------------------------------------------------------------------------------------------------
+__global__ void k_gae_scan(int N, int T, int P, const float *r, const float *v, const float *active, float gamma, float lamda,
+                           float *adv, float *v_target, double *stats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    double s = 0.0, s2 = 0.0;
+    if (idx < N * P) {
+        const int n = idx / P, p = idx - n * P;
+        float gae = 0.f;
+        for (int t = T - 1; t >= 0; t--) {
+            const size_t o = ((size_t)n * T + t) * P + p;
+            const float vt = v[((size_t)n * (T + 1) + t) * P + p], vn = v[((size_t)n * (T + 1) + t + 1) * P + p];
+            float delta = (r[o] + gamma * vn - vt) * active[o];
+            gae = delta + gamma * lamda * gae;
+            adv[o] = gae;
+            v_target[o] = gae + vt;
+            s += (double)gae;
+            s2 += (double)gae * (double)gae;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); s2 += __shfl_xor(s2, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], s); atomicAdd(&stats[1], s2); }
+}
+
+__global__ void k_gae_finalize(int64_t n, double *stats) {
+    double mean = stats[0] / (double)n;
+    double var = (stats[1] - (double)n * mean * mean) / (double)(n - 1);  // unbiased, torch.std default
+    stats[2] = mean;
+    stats[3] = sqrt(var > 0.0 ? var : 0.0);
+}
+
+__global__ void k_gae_center(int64_t n, const float *adv, double *stats) {
+    // second pass for a numerically robust variance: sum (x - mean)^2
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double d = 0.0;
+    if (i < n) { double x = (double)adv[i] - stats[2]; d = x * x; }
+    for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&stats[1], d);
+}
+
+__global__ void k_gae_std(int64_t n, double *stats) { stats[3] = sqrt(stats[1] / (double)(n - 1)); }
+
+__global__ void k_gae_norm(int64_t n, float *adv, const float *active, const double *stats) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float mean = (float)stats[2], sd = (float)stats[3];
+        adv[i] = (adv[i] - mean) / (sd + 1e-5f) * active[i];
+    }
+}
+
+// ---- Categorical sample / argmax ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *o) {
+    for (int i = 0; i < 10; i++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__global__ void k_categorical(int R, int A, const float *probs, uint64_t seed, uint64_t offset, int greedy, int32_t *action, float *logp) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float *p = probs + (size_t)r * A;
+    float tot = 0.f;
+    for (int k = 0; k < A; k++) tot += p[k];
+    int a = 0;
+    if (greedy) {
+        float best = p[0];
+        for (int k = 1; k < A; k++) if (p[k] > best) { best = p[k]; a = k; }
+    } else {
+        uint32_t o[4];
+        const uint64_t ctr = offset + (uint64_t)r;
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        const float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f) * tot;  // (0, tot)
+        float cum = 0.f;
+        a = A - 1;
+        for (int k = 0; k < A; k++) { cum += p[k]; if (u < cum) { a = k; break; } }
+    }
+    action[r] = a;
+    if (logp) {
+        // Categorical(probs=p).log_prob(a): log(clamp(p / sum p, eps, 1 - eps)), eps = FLT_EPSILON
+        float pn = p[a] / tot;
+        pn = fminf(fmaxf(pn, 1.1920929e-07f), 1.f - 1.1920929e-07f);
+        logp[r] = logf(pn);
+    }
+}
+
+size_t msg_lds_bytes(int P, int K) { return sizeof(float) * (size_t)(K * 4 + ((P * K + 3) & ~3) + P * 4 + P * 4 + MAX_P + 4); }
+
+int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, const void *adj, const void *kvalid, const void *e) {
+    if (R < 0 || P < 1 || P > MAX_P || K < 1 || E < 64 || E > 256 || (E & 63) || (din != 4 && din != 8) || q_div < 1) return MO_ERR_BAD_ARG;
+    if (adj_mode == MO_ADJ_TENSOR && !adj) return MO_ERR_BAD_ARG;
+    if (adj_mode == MO_ADJ_VALID && !kvalid) return MO_ERR_BAD_ARG;
+    if (adj_mode < 0 || adj_mode > 2) return MO_ERR_BAD_ARG;
+    if (din == 8 && !e) return MO_ERR_BAD_ARG;
+    if (msg_lds_bytes(P, K) > 64 * 1024) return MO_ERR_BAD_ARG;
+    return 0;
+}
+
+constexpr int BWD_BLOCKS = 2048;
+
+}  // namespace
+
+extern "C" {
+
+int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, const float *q, int32_t q_div,
+                     const float *e, const float *adj, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
+                     float *out, void *stream) {
+    int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
+    if (rc) return rc;
+    if (R == 0) return 0;
+    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, kvalid, W, b};
+    const int grid = R < 8192 ? R : 8192;
+    hipLaunchKernelGGL(k_msg_agg_fwd, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
+    return (int)hipGetLastError();
+}
+
+int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD_BLOCKS * (din + 1) * E * sizeof(float); }
+
+int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, const float *q, int32_t q_div,
+                     const float *e, const float *adj, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
+                     const float *gout, float *dW, float *db, void *workspace, void *stream) {
+    int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
+    if (rc) return rc;
+    if (!workspace || !gout || !dW || !db) return MO_ERR_BAD_ARG;
+    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, kvalid, W, b};
+    const int grid = R < BWD_BLOCKS ? (R > 0 ? R : 1) : BWD_BLOCKS;
+    hipLaunchKernelGGL(k_msg_agg_bwd, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);
+    const int tot = (din + 1) * E;
+    hipLaunchKernelGGL(k_msg_agg_bwd_reduce, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, grid, E, din,
+                       (const float *)workspace, dW, db);
+    return (int)hipGetLastError();
+}
+
+int gae_advnorm(int32_t N, int32_t T, int32_t P, const float *r, const float *v, const float *active, float gamma, float lamda,
+                int32_t use_adv_norm, float *adv, float *v_target, double *stats, void *stream) {
+    if (N < 1 || T < 1 || P < 1 || !r || !v || !active || !adv || !v_target || !stats) return MO_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(double), s);
+    if (e != hipSuccess) return (int)e;
+    const int64_t n = (int64_t)N * T * P;
+    hipLaunchKernelGGL(k_gae_scan, dim3((N * P + 255) / 256), dim3(256), 0, s, N, T, P, r, v, active, gamma, lamda, adv, v_target, stats);
+    if (use_adv_norm) {
+        hipLaunchKernelGGL(k_gae_finalize, dim3(1), dim3(1), 0, s, n, stats);
+        e = hipMemsetAsync(stats + 1, 0, sizeof(double), s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k_gae_center, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, adv, stats);
+        hipLaunchKernelGGL(k_gae_std, dim3(1), dim3(1), 0, s, n, stats);
+        hipLaunchKernelGGL(k_gae_norm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, adv, active, stats);
+    }
+    return (int)hipGetLastError();
+}
+
+int categorical_sample(int32_t R, int32_t A, const float *probs, uint64_t seed, uint64_t offset, int32_t greedy, int32_t *action,
+                       float *logp, void *stream) {
+    if (R < 0 || A < 1 || !probs || !action) return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(k_categorical, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, A, probs, seed, offset, greedy, action, logp);
+    return (int)hipGetLastError();
+}
+
+const char *mappo_ops_error_string(int code) {
+    if (code == MO_ERR_BAD_ARG) return "mappo_ops: bad argument";
+    return hipGetErrorString((hipError_t)code);
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+"""DHGN encoder + GRU actor / critic with the reference's parameter names and initialisation stream.
+
+Mirrors (reference paths) DHGN/mappo_parallel.py:116-387 `DHGN`, :390-474 `SharedActor`, :477-545 `SharedCritic`.
+* state_dict keys, shapes and `.parameters()` order equal the reference's (checkpoint / gradient-list contract,
+  SURVEY 8a M1-M5); modules are constructed in the reference's order with the same torch initialisers, so the same
+  `torch.manual_seed` yields bit-identical initial weights.
+* forward is written on whole tensors (rows = environments or environment-steps) instead of the reference's
+  DataLoader(batch_size=1) plumbing, and the relation message + mean aggregation runs in the fused HIP op
+  `ops.msg_agg` (csrc/mappo_ops.hip).  Only the working aggregator ('mean') exists.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils import spectral_norm
+
+from . import ops
+
+
+def _ortho_linear(n_in, n_out):
+    """reference preproc_layer without spectral norm (DHGN/mappo_parallel.py:19-31): default Linear init is drawn
+    first (it consumes the generator), then weights are re-drawn orthogonal (gain 1) and the bias zeroed."""
+    layer = nn.Linear(n_in, n_out)
+    for name, param in layer.named_parameters():
+        if "bias" in name:
+            nn.init.constant_(param, 0)
+        elif "weight" in name:
+            nn.init.orthogonal_(param, gain=1.0)
+    return layer
+
+
+def _make_linear(n_in, n_out, is_sn):
+    # `preproc_layer(a, b) if is_sn else nn.Linear(a, b)` -- note is_sn is NOT forwarded
+    return _ortho_linear(n_in, n_out) if is_sn else nn.Linear(n_in, n_out)
+
+
+class DHGN(nn.Module):
+    def __init__(self, input_dim, embedding_dim, is_sn, algo_config, device=None):
+        super().__init__()
+        for key in ("vertex_level_aggregator", "fcra_aggregator"):
+            if getattr(algo_config, key) != "mean":
+                raise NotImplementedError(f"{key}={getattr(algo_config, key)!r}: only 'mean' works in the reference too")
+        self.ReLU = nn.ReLU()
+        self.MSG_layers = nn.ModuleList()
+        self.AGG_layers = nn.ModuleDict()
+        self.FCRA_layers = nn.ModuleList()
+        self.alpha = nn.ModuleDict()
+        self.depth = int(algo_config.depth)
+        self.num_relation = int(algo_config.num_relation)
+        if self.num_relation != 3:
+            raise NotImplementedError("num_relation must be 3 (defender, evader, obstacle)")
+        self.input_dim, self.embedding_dim = input_dim, embedding_dim
+        E = embedding_dim
+        self.semantic_layer = _make_linear(3 * E + input_dim, E, is_sn)
+        for r in range(self.num_relation):
+            self.MSG_layers.append(_make_linear(2 * input_dim if r == 0 else input_dim, E, is_sn))
+        for _ in range(self.depth):
+            self.FCRA_layers.append(_make_linear(2 * E, E, is_sn))
+        self.AGG_layers["AGG_vertex_0"] = _make_linear(E, E, is_sn)  # shared by the three relations (:151-152, :278)
+        for k in range(self.depth):
+            self.AGG_layers[f"AGG_fcra_{k}"] = _make_linear(E, E, is_sn)
+
+    # -- encoder (:241-304) ----------------------------------------------------------------------------
+    def encoder(self, p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid=None, q_div=1):
+        """p (R,P,4), e (R,1,4), o (R/q_div,O,4), adj_* (R,P,{P,1,O}) -> h0 (R,P,E).
+        is_critic: adjacency := ones (AttributeDataset, :64-65); in a batched rollout the obstacle relation uses ones
+        over the first o_kvalid[row] (real) obstacles, in training over all padded slots."""
+        e2 = e.reshape(e.shape[0], 4)
+        mode = ops.ADJ_ONES if is_critic else ops.ADJ_TENSOR
+        m0 = ops.msg_agg(p, p, e2, adj_p, self.MSG_layers[0].weight, self.MSG_layers[0].bias, mode)
+        m1 = ops.msg_agg(p, e, None, adj_e, self.MSG_layers[1].weight, self.MSG_layers[1].bias, mode)
+        mode_o = mode
+        if is_critic and o_kvalid is not None:
+            mode_o = ops.ADJ_VALID
+        m2 = ops.msg_agg(p, o, None, adj_o, self.MSG_layers[2].weight, self.MSG_layers[2].bias, mode_o, o_kvalid, q_div)
+        emb = F.relu(self.AGG_layers["AGG_vertex_0"](torch.stack((m0, m1, m2), 0)))
+        x = torch.cat((p, emb[0], emb[1], emb[2]), dim=-1)
+        return self.semantic_layer(x)
+
+    # -- fixed-depth recursive aggregation over neighbours' historical embeddings (:204-233) --------------
+    def fcra(self, h0, hist, adj_p, is_critic):
+        """hist: sequence of `depth` tensors (R,P,E), hop k = hist[k] (k = 0 is the most recent)."""
+        h = h0
+        if self.depth == 0:
+            return h
+        adj = torch.ones_like(adj_p) if is_critic else adj_p
+        abar = F.normalize(adj, p=1, dim=-1)
+        for k in range(self.depth):
+            agg = F.relu(self.AGG_layers[f"AGG_fcra_{k}"](torch.matmul(abar, hist[k])))
+            h = F.relu(self.FCRA_layers[k](torch.cat((agg, h), dim=-1)))
+        return h
+
+    def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1):
+        h0 = self.encoder(p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid, q_div)
+        return self.fcra(h0, hist, adj_p, is_critic)
+
+
+class _Trunk(nn.Module):
+    """shared_net -> GRU -> Mean, common to actor and critic."""
+
+    def _rollout_features(self, embedding, hidden_state):
+        R, P, E = embedding.shape
+        feat, hidden_state = self.GRU(embedding.reshape(1, R * P, E), hidden_state)
+        return feat.reshape(R, P, self.rnn_hidden_dim), hidden_state
+
+    def _sequence_features(self, embedding, batch, steps):
+        P = embedding.shape[1]
+        x = embedding.reshape(batch, steps, P, self.rnn_input_dim).permute(1, 0, 2, 3).reshape(steps, batch * P, self.rnn_input_dim)
+        h0 = torch.zeros(self.num_layers, batch * P, self.rnn_hidden_dim, dtype=x.dtype, device=x.device)
+        feat, _ = self.GRU(x.contiguous(), h0)
+        return feat.reshape(steps, batch, P, self.rnn_hidden_dim).permute(1, 0, 2, 3)
+
+    def get_weights(self):
+        return {k: v.cpu() for k, v in self.state_dict().items()}
+
+    def set_weights(self, weights):
+        self.load_state_dict(weights)
+
+    def get_gradients(self):
+        """list in .parameters() order, None allowed (reference :464-469)"""
+        return [None if p.grad is None else p.grad.data.cpu().numpy() for p in self.parameters()]
+
+    def set_gradients(self, gradients, device):
+        for g, p in zip(gradients, self.parameters()):
+            if g is not None:
+                p.grad = torch.as_tensor(g).to(device)
+
+
+class SharedActor(_Trunk):
+    def __init__(self, shared_net, rnn_input_dim, action_dim, num_layers, rnn_hidden_dim, is_sn=False):
+        super().__init__()
+        self.shared_net = shared_net
+        self.num_layers = num_layers
+        self.rnn_input_dim = rnn_input_dim
+        self.rnn_hidden_dim = rnn_hidden_dim
+        self.GRU = nn.GRU(rnn_input_dim, rnn_hidden_dim, num_layers)
+        self.Mean = _make_linear(rnn_hidden_dim, action_dim, is_sn)
+
+    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None):
+        """mode 0 (one step for R environments): returns prob (R,P,A), hidden, embedding (R,P,E)   (:422-425)
+        mode 1 (sequences, rows ordered (episode, step)): returns prob (batch,steps,P,A), None, embedding  (:426-437)"""
+        emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], obs["o_adj"], hist,
+                              False, None, obs.get("q_div", 1))
+        if mode == 0:
+            feat, hidden_state = self._rollout_features(emb, hidden_state)
+        else:
+            feat, hidden_state = self._sequence_features(emb, batch, steps), None
+        prob = torch.softmax(self.Mean(feat), dim=-1)
+        return prob, hidden_state, emb
+
+    def get_logprob_and_entropy(self, obs, hist, action, batch, steps):
+        """Categorical(prob).log_prob / entropy (:451-456)"""
+        prob, _, _ = self.forward(obs, hist, None, 1, batch, steps)
+        dist = torch.distributions.Categorical(prob)
+        return dist.log_prob(action), dist.entropy()
+
+
+class SharedCritic(_Trunk):
+    def __init__(self, shared_net, rnn_input_dim, value_dim, num_layers, rnn_hidden_dim, is_sn=False):
+        super().__init__()
+        self.shared_net = shared_net
+        self.num_layers = num_layers
+        self.rnn_input_dim = rnn_input_dim
+        self.rnn_hidden_dim = rnn_hidden_dim
+        self.GRU = nn.GRU(rnn_input_dim, rnn_hidden_dim, num_layers)
+        head = _ortho_linear(rnn_hidden_dim, value_dim)
+        self.Mean = spectral_norm(head) if is_sn else head  # the only spectrally normalised layer (:485)
+
+    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, rollout=False):
+        kvalid = obs.get("o_kvalid") if rollout else None
+        emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], obs["o_adj"], hist,
+                              True, kvalid, obs.get("q_div", 1))
+        if mode == 0:
+            feat, hidden_state = self._rollout_features(emb, hidden_state)
+            return self.Mean(feat), hidden_state, emb
+        feat = self._sequence_features(emb, batch, steps)
+        return self.Mean(feat)
+
+
+def build_actor_critic(cfg, device):
+    """encoder -> actor -> critic, the construction order of MAPPO.__init__ (:582-616); encoder is shared."""
+    sn = cfg.algo.use_spectral_norm
+    enc = DHGN(cfg.env.state_dim, cfg.algo.embedding_dim, sn, cfg.algo, device)
+    actor = SharedActor(enc, cfg.algo.embedding_dim, cfg.env.action_dim, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
+    critic = SharedCritic(enc, cfg.algo.embedding_dim, 1, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
+    return actor.to(device), critic.to(device)

@@ -1,0 +1,152 @@
+"""ctypes binding of libmappo_ops.so (include/mappo_ops.h) with autograd glue.
+
+The ops run only on the GPU through the HIP library; on a CPU tensor or without the built library they raise
+(there is deliberately no eager fallback).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
+EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
+           "mappo_ops_error_string")
+
+_lib = None
+
+
+def lib_path():
+    return _build.lib_path("libmappo_ops.so")
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                               "the fused MAPPO ops have no fallback")
+        L = C.CDLL(path)
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        L.dhgn_msg_agg_fwd.argtypes = [i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+        L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
+        L.dhgn_msg_agg_bwd_workspace.restype = i64
+        L.gae_advnorm.argtypes = [i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
+        L.categorical_sample.argtypes = [i32, i32, vp, C.c_uint64, C.c_uint64, i32, vp, vp, vp]
+        L.mappo_ops_error_string.argtypes = [C.c_int]
+        L.mappo_ops_error_string.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {load_library().mappo_ops_error_string(rc).decode()} (code {rc})")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the fused HIP ops run on the GPU only (no CPU fallback)")
+
+
+_workspaces = {}
+
+
+def _workspace(device, E, din):
+    key = (device, E, din)
+    ws = _workspaces.get(key)
+    if ws is None:
+        n = load_library().dhgn_msg_agg_bwd_workspace(E, din)
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+class _MsgAgg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, q, e, adj, kvalid, W, b, adj_mode, q_div):
+        L = load_library()
+        _need_gpu(p, "dhgn_msg_agg")
+        R, P = p.shape[0], p.shape[1]
+        K = q.shape[1]
+        E, din = W.shape
+        assert p.dtype == torch.float32 and p.is_contiguous() and p.shape[2] == 4
+        assert q.is_contiguous() and q.shape[2] == 4 and q.shape[0] * q_div == R
+        if adj is not None:
+            assert adj.is_contiguous() and adj.shape == (R, P, K) and adj.dtype == torch.float32
+        if e is not None:
+            assert e.is_contiguous() and e.shape == (R, 4)
+        if kvalid is not None:
+            assert kvalid.dtype == torch.int32 and kvalid.is_contiguous() and kvalid.shape[0] * q_div == R
+        Wc, bc = W.detach().contiguous(), b.detach().contiguous()
+        out = torch.empty((R, P, E), dtype=torch.float32, device=p.device)
+        _check(L.dhgn_msg_agg_fwd(R, P, K, E, din, _ptr(p), _ptr(q), q_div, _ptr(e), _ptr(adj), adj_mode, _ptr(kvalid),
+                                  _ptr(Wc), _ptr(bc), _ptr(out), _stream()), "dhgn_msg_agg_fwd")
+        ctx.save_for_backward(p, q, e, adj, kvalid, Wc, bc)
+        ctx.meta = (adj_mode, q_div)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = load_library()
+        p, q, e, adj, kvalid, W, b = ctx.saved_tensors
+        adj_mode, q_div = ctx.meta
+        R, P = p.shape[0], p.shape[1]
+        K = q.shape[1]
+        E, din = W.shape
+        gout = gout.contiguous()
+        dW = torch.empty_like(W)
+        db = torch.empty_like(b)
+        ws = _workspace(p.device, E, din)
+        _check(L.dhgn_msg_agg_bwd(R, P, K, E, din, _ptr(p), _ptr(q), q_div, _ptr(e), _ptr(adj), adj_mode, _ptr(kvalid), _ptr(W),
+                                  _ptr(b), _ptr(gout), _ptr(dW), _ptr(db), _ptr(ws), _stream()), "dhgn_msg_agg_bwd")
+        return None, None, None, None, None, dW, db, None, None
+
+
+def msg_agg(p, q, e, adj, W, b, adj_mode=ADJ_TENSOR, kvalid=None, q_div=1):
+    """sum_j abar_ij ReLU(W [p_i - q_j, p_i - e] + b): DHGN.coordinate/message/mean_operator fused
+    (reference DHGN/mappo_parallel.py:235-239, 323-334, 346-347).  p (R,P,4), q (R/q_div,K,4), e (R,4)|None,
+    adj (R,P,K)|None -> (R,P,E)."""
+    return _MsgAgg.apply(p, q, e, adj if adj_mode == ADJ_TENSOR else None, kvalid if adj_mode == ADJ_VALID else None, W, b,
+                         adj_mode, q_div)
+
+
+def gae_advnorm(r, v, active, gamma, lamda, use_adv_norm=True):
+    """GAE + v_target + advantage normalisation (reference DHGN/mappo_parallel.py:643-658). r/active (N,T,P), v (N,T+1,P)."""
+    L = load_library()
+    _need_gpu(r, "gae_advnorm")
+    N, T, P = r.shape
+    assert v.shape == (N, T + 1, P) and active.shape == r.shape
+    r, v, active = r.contiguous(), v.contiguous(), active.contiguous()
+    adv = torch.empty_like(r)
+    v_target = torch.empty_like(r)
+    stats = torch.empty(4, dtype=torch.float64, device=r.device)
+    _check(L.gae_advnorm(N, T, P, _ptr(r), _ptr(v), _ptr(active), float(gamma), float(lamda), 1 if use_adv_norm else 0,
+                         _ptr(adv), _ptr(v_target), _ptr(stats), _stream()), "gae_advnorm")
+    return adv, v_target
+
+
+def categorical_sample(probs, seed, offset, greedy=False):
+    """Categorical(probs).sample() and log_prob, or argmax when greedy (reference DHGN/mappo_parallel.py:442-448)."""
+    L = load_library()
+    _need_gpu(probs, "categorical_sample")
+    shape = probs.shape[:-1]
+    A = probs.shape[-1]
+    pr = probs.reshape(-1, A).contiguous()
+    R = pr.shape[0]
+    action = torch.empty(R, dtype=torch.int32, device=probs.device)
+    logp = torch.empty(R, dtype=torch.float32, device=probs.device)
+    _check(L.categorical_sample(R, A, _ptr(pr), int(seed), int(offset), 1 if greedy else 0, _ptr(action), _ptr(logp), _stream()),
+           "categorical_sample")
+    return action.reshape(shape), logp.reshape(shape)

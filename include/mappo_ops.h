@@ -1,0 +1,73 @@
+/*
+ * mappo_ops.h -- C ABI of the MI355X (gfx950) fused ops of the MAPPO update/rollout path.
+ *
+ * These replace torch op sequences of the reference (DHGN/mappo_parallel.py); there is no native boundary in the
+ * reference, the seam is the Python methods cited per entry point.  All pointers are DEVICE pointers owned by the
+ * caller, kernels are enqueued on the caller's hipStream_t (passed as void*), return value 0 == success
+ * (otherwise a hipError_t / MO_ERR_* code).  fp32 throughout (the 1e-4 parity tolerance rules out bf16).
+ */
+#ifndef MAPPO_OPS_H
+#define MAPPO_OPS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MO_ERR_BAD_ARG 20001
+
+/* adjacency source of dhgn_msg_agg_* */
+enum { MO_ADJ_TENSOR = 0,   /* actor: the observed adjacency                                            */
+       MO_ADJ_ONES = 1,     /* critic: torch.ones_like(adj) over all K neighbours (AttributeDataset, :64-65) */
+       MO_ADJ_VALID = 2 };  /* critic in a batched rollout: ones over the first kvalid[row] real neighbours  */
+
+/*
+ * Vertex-level message + mean aggregation of one DHGN relation, never materialising the (R,P,K,E) message:
+ *   out[r,i,:] = sum_j abar[r,i,j] * ReLU( W[:, :4] (p[r,i] - q[r',j]) + W[:, 4:8] (p[r,i] - e[r]) + b )
+ *   abar = adj / max(sum_j |adj|, 1e-12)            (F.normalize(adj, p=1, dim=-1))
+ * i.e. DHGN.coordinate + DHGN.message + the matmul of DHGN.mean_operator (DHGN/mappo_parallel.py:235-239,
+ * 323-334, 346-347) for relation 0 (q = p, din = 8, e given), 1 (q = e, K = 1) and 2 (q = obstacles).
+ *   R rows, P agents, K neighbours, E features (multiple of 64, <= 256), din in {4, 8};
+ *   p [R][P][4]; q [R/q_div][K][4] (q_div p-rows share one q-row: obstacles are static over an episode);
+ *   e [R][4] or NULL (din == 4); adj [R][P][K] (MO_ADJ_TENSOR) ; kvalid [R/q_div] (MO_ADJ_VALID);
+ *   W [E][din]; b [E]; out [R][P][E].
+ */
+int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, const float *q, int32_t q_div,
+                     const float *e, const float *adj, int32_t adj_mode, const int32_t *kvalid, const float *W,
+                     const float *b, float *out, void *stream);
+
+/*
+ * Backward of the above w.r.t. W and b (the inputs are data, they carry no gradient): recomputes the
+ * pre-activation, masks with ReLU', reduces over all (r,i,j) without atomics (per-workgroup partials in
+ * `workspace`, then one deterministic second pass).  gout [R][P][E]; dW [E][din]; db [E] are OVERWRITTEN.
+ * workspace: at least dhgn_msg_agg_bwd_workspace(E, din) bytes.
+ */
+int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din);
+int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, const float *q, int32_t q_div,
+                     const float *e, const float *adj, int32_t adj_mode, const int32_t *kvalid, const float *W,
+                     const float *b, const float *gout, float *dW, float *db, void *workspace, void *stream);
+
+/*
+ * GAE reverse scan + value target + advantage normalisation (DHGN/mappo_parallel.py:643-658):
+ *   delta = (r + gamma v[:,1:] - v[:,:-1]) * active ; gae_t = delta_t + gamma lamda gae_{t+1}
+ *   v_target = adv + v[:,:-1] ; if use_adv_norm: adv = (adv - mean) / (std_unbiased + 1e-5) * active
+ * r, active, adv, v_target [N][T][P]; v [N][T+1][P].  Statistics over all N*T*P elements, accumulated in f64.
+ * stats (device, 4 doubles: sum, sumsq, mean, std) is scratch + output.
+ */
+int gae_advnorm(int32_t N, int32_t T, int32_t P, const float *r, const float *v, const float *active, float gamma,
+                float lamda, int32_t use_adv_norm, float *adv, float *v_target, double *stats, void *stream);
+
+/*
+ * Categorical(probs).sample() + log_prob for a batch of rows (DHGN/mappo_parallel.py:446-448) with a counter-based
+ * generator (Philox4x32-10; stream = (seed, offset + row)): probs [R][A] -> action [R] int32, logp [R].
+ * greedy != 0 gives probs.argmax(-1) instead (choose_action(deterministic=True), :442-444; first maximum wins).
+ */
+int categorical_sample(int32_t R, int32_t A, const float *probs, uint64_t seed, uint64_t offset, int32_t greedy,
+                       int32_t *action, float *logp, void *stream);
+
+const char *mappo_ops_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
