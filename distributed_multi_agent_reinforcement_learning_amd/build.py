@@ -10,7 +10,7 @@ INCLUDE = os.path.join(ROOT, "include")
 
 # name -> (sources, extra flags).  -ffp-contract=off: the f64 simulator must not be FMA-contracted (see pe_env.hip).
 LIBS = {
-    "libpe_env.so": (["pe_env.hip"], ["-ffp-contract=off"]),
+    "libpe_env.so": (["pe_env.hip", "pe_reset.cpp"], ["-ffp-contract=off", "-pthread"]),
     "libmappo_ops.so": (["mappo_ops.hip"], []),
 }
 

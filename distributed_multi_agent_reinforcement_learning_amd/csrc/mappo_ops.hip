@@ -16,6 +16,7 @@ constexpr int MAX_P = 16;
 struct MsgArgs {
     int R, P, K, E, din, q_div, adj_mode;
     const float *p, *q, *e, *adj;
+    int64_t p_rs, q_rs, e_rs, adj_rs;  // row strides in elements (rows may be slices of (N, T, ...) buffers)
     const int32_t *kvalid;
     const float *W, *b;
 };
@@ -25,15 +26,15 @@ __device__ __forceinline__ void stage_row(const MsgArgs &a, int r, float *s_p, f
                                           int tid, int nthr) {
     const int P = a.P, K = a.K;
     const int qr = r / a.q_div;
-    for (int i = tid; i < P * 4; i += nthr) s_p[i] = a.p[(size_t)r * P * 4 + i];
+    for (int i = tid; i < P * 4; i += nthr) s_p[i] = a.p[(size_t)r * a.p_rs + i];
     {
-        const float4 *src = (const float4 *)(a.q + (size_t)qr * K * 4);
+        const float4 *src = (const float4 *)(a.q + (size_t)qr * a.q_rs);
         float4 *dst = (float4 *)s_q;
         for (int i = tid; i < K; i += nthr) dst[i] = src[i];
     }
     if (a.adj_mode == MO_ADJ_TENSOR) {
-        const float *src = a.adj + (size_t)r * P * K;
-        if (((P * K) & 3) == 0) {
+        const float *src = a.adj + (size_t)r * a.adj_rs;
+        if (((P * K) & 3) == 0 && (a.adj_rs & 3) == 0) {
             for (int i = tid; i < (P * K) >> 2; i += nthr) ((float4 *)s_adj)[i] = ((const float4 *)src)[i];
         } else {
             for (int i = tid; i < P * K; i += nthr) s_adj[i] = src[i];
@@ -51,7 +52,7 @@ __device__ __forceinline__ void stage_row(const MsgArgs &a, int r, float *s_p, f
         }
         s_inv[tid] = 1.f / fmaxf(s, 1e-12f);
         if (a.din == 8) {
-            for (int k = 0; k < 4; k++) s_pe[tid * 4 + k] = s_p[tid * 4 + k] - a.e[(size_t)r * 4 + k];
+            for (int k = 0; k < 4; k++) s_pe[tid * 4 + k] = s_p[tid * 4 + k] - a.e[(size_t)r * a.e_rs + k];
         }
     }
     __syncthreads();
@@ -268,13 +269,14 @@ constexpr int BWD_BLOCKS = 2048;
 
 extern "C" {
 
-int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, const float *q, int32_t q_div,
-                     const float *e, const float *adj, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
-                     float *out, void *stream) {
+int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
+                     int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const float *adj, int64_t adj_rs, int32_t adj_mode,
+                     const int32_t *kvalid, const float *W, const float *b, float *out, void *stream) {
     int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
     if (rc) return rc;
     if (R == 0) return 0;
-    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, kvalid, W, b};
+    if (q_rs & 3) return MO_ERR_BAD_ARG;
+    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, p_rs, q_rs, e_rs, adj_rs, kvalid, W, b};
     const int grid = R < 8192 ? R : 8192;
     hipLaunchKernelGGL(k_msg_agg_fwd, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
     return (int)hipGetLastError();
@@ -282,13 +284,15 @@ int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
 
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD_BLOCKS * (din + 1) * E * sizeof(float); }
 
-int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, const float *q, int32_t q_div,
-                     const float *e, const float *adj, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
-                     const float *gout, float *dW, float *db, void *workspace, void *stream) {
+int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
+                     int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const float *adj, int64_t adj_rs, int32_t adj_mode,
+                     const int32_t *kvalid, const float *W, const float *b, const float *gout, float *dW, float *db,
+                     void *workspace, void *stream) {
     int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
     if (rc) return rc;
     if (!workspace || !gout || !dW || !db) return MO_ERR_BAD_ARG;
-    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, kvalid, W, b};
+    if (q_rs & 3) return MO_ERR_BAD_ARG;
+    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, p_rs, q_rs, e_rs, adj_rs, kvalid, W, b};
     const int grid = R < BWD_BLOCKS ? (R > 0 ? R : 1) : BWD_BLOCKS;
     hipLaunchKernelGGL(k_msg_agg_bwd, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);
     const int tot = (din + 1) * E;

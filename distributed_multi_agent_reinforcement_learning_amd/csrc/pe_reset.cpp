@@ -1,0 +1,274 @@
+// pe_reset.cpp -- host side of Pursuit_Env.reset(): map, boundary obstacles, target, defenders, evader.
+//
+// Replaces (reference paths) pursuit_env.py:60-73, base_env.py:37-162, Occupied_Grid_Map.py:46-62,119-166 and the
+// skimage 'inner' boundary of pursuit_env.py:18-27 for N environments, multi-threaded.  Each environment owns the two
+// generator streams the reference consumes -- Python's `random` (Mersenne Twister + randbelow) and numpy's legacy
+// RandomState (rand / normal) -- re-implemented bit-exactly, so environment n reset from `random.seed(s);
+// np.random.seed(s)` starts exactly like the reference seeded with s, and keeps consuming its streams over
+// episodes the way one reference Worker does (the targets the evader did not reach are un-drawn again).
+// C ABI: include/pe_env.h (pe_resetter_*).
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "pe_env.h"
+
+namespace {
+
+struct MT19937 {
+    uint32_t mt[624];
+    int idx;
+    void init_genrand(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    void init_by_array(const uint32_t *key, int len) {
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        int k = 624 > len ? 624 : len;
+        for (; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            i++; j++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (j >= len) j = 0;
+        }
+        for (k = 623; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            i++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+        idx = 624;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; k++) {
+                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+
+// CPython random.Random seeded with a non-negative int (Lib/random.py seed -> _randommodule.c init_by_array)
+struct PyRandom {
+    MT19937 g;
+    void seed(uint64_t a) {
+        uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+        g.init_by_array(key, key[1] ? 2 : 1);
+    }
+    uint32_t getrandbits(int k) { return g.next() >> (32 - k); }  // 1 <= k <= 32
+    uint32_t randbelow(uint32_t n) {                              // _randbelow_with_getrandbits
+        int k = 0;
+        for (uint32_t v = n; v; v >>= 1) k++;
+        uint32_t r = getrandbits(k);
+        while (r >= n) r = getrandbits(k);
+        return r;
+    }
+    int randint(int a, int b) { return a + (int)randbelow((uint32_t)(b - a + 1)); }
+};
+
+// numpy.random.RandomState (legacy) seeded with a 32-bit int: rand(), normal()
+struct NpRandom {
+    MT19937 g;
+    bool has_gauss = false;
+    double gauss = 0.0;
+    void seed(uint32_t s) { g.init_genrand(s); has_gauss = false; gauss = 0.0; }
+    double random_sample() {
+        uint32_t a = g.next() >> 5, b = g.next() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    double legacy_gauss() {
+        if (has_gauss) { has_gauss = false; double t = gauss; gauss = 0.0; return t; }
+        double f, x1, x2, r2;
+        do {
+            x1 = 2.0 * random_sample() - 1.0;
+            x2 = 2.0 * random_sample() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        f = sqrt(-2.0 * log(r2) / r2);
+        gauss = f * x1;
+        has_gauss = true;
+        return f * x2;
+    }
+    double normal(double loc, double scale) { return loc + scale * legacy_gauss(); }
+};
+
+inline int py_round(double v) { return (int)nearbyint(v); }
+inline double norm2(double a, double b) { return sqrt(fma(b, b, a * a)); }
+
+struct EnvRng {
+    PyRandom py;
+    NpRandom np;
+    PyRandom py_before_tape;  // snapshot taken before the tape of the running episode was drawn
+    bool has_tape = false;
+};
+
+struct Resetter {
+    pe_config cfg;
+    pe_reset_params prm;
+    int N;
+    std::vector<EnvRng> rng;
+    std::vector<uint8_t> inflated;  // [N][W*H] static map inflated by 2 of the running episode (target re-draws)
+};
+
+void inflate(int W, int H, uint8_t *g, int x, int y, int ext) {
+    for (int xx = x - ext; xx <= x + ext; xx++)
+        for (int yy = y - ext; yy <= y + ext; yy++)
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H) g[xx * H + yy] = 1;
+}
+
+void draw_target(int W, int H, const uint8_t *infl, PyRandom &py, int32_t *out) {  // base_env.py:52-70
+    for (;;) {
+        int tx = py.randint(0, W - 1), ty = py.randint(0, H - 1);
+        if (infl[tx * H + ty] == 0) { out[0] = tx; out[1] = ty; return; }
+    }
+}
+
+void reset_one(Resetter &R, int n, int consumed, const pe_host_init_out &o) {
+    const pe_config &c = R.cfg;
+    const int W = c.W, H = c.H, WH = W * H, P = c.P, O = c.O;
+    EnvRng &rg = R.rng[n];
+    uint8_t *infl_static = R.inflated.data() + (size_t)n * WH;
+    if (rg.has_tape) {
+        // the reference draws a new target only when the evader reaches one: replay exactly `consumed` draws
+        rg.py = rg.py_before_tape;
+        int32_t tmp[2];
+        for (int k = 0; k < consumed; k++) draw_target(W, H, infl_static, rg.py, tmp);
+    }
+    uint8_t *grid = o.grid + (size_t)n * WH;
+    memset(grid, 0, WH);
+    // init_map -> initailize_obstacle -> add_blocker_type('r', (6, 7)) : x, y in [-3, 3) (Occupied_Grid_Map.py:46-62)
+    for (int b = 0; b < R.prm.num_blocks; b++) {
+        rg.py.randbelow(1);  // random.randrange(len(shape)) with one shape
+        double cx = rg.np.normal(R.prm.center[0], R.prm.variance), cy = rg.np.normal(R.prm.center[1], R.prm.variance);
+        for (int x = -3; x < 3; x++)
+            for (int y = -3; y < 3; y++) {
+                int px = py_round((double)x + cx), py = py_round((double)y + cy);
+                if (px >= 0 && px < W && py >= 0 && py < H) grid[px * H + py] = 1;
+            }
+    }
+    std::vector<uint8_t> infl(WH);
+    memcpy(infl.data(), grid, WH);
+    for (int x = 0; x < W; x++)
+        for (int y = 0; y < H; y++)
+            if (grid[x * H + y]) inflate(W, H, infl.data(), x, y, 2);
+    memcpy(infl_static, infl.data(), WH);
+    // inner boundary (find_boundaries mode='inner', connectivity 1, mirrored edges): obstacle cell with a free 4-neighbour
+    int32_t *obs = o.obs_xy + (size_t)n * O * 2;
+    memset(obs, 0, sizeof(int32_t) * O * 2);
+    int n_obs = 0;
+    for (int x = 0; x < W; x++)
+        for (int y = 0; y < H; y++) {
+            if (!grid[x * H + y]) continue;
+            bool fr = (x > 0 && !grid[(x - 1) * H + y]) || (x < W - 1 && !grid[(x + 1) * H + y]) || (y > 0 && !grid[x * H + y - 1]) ||
+                      (y < H - 1 && !grid[x * H + y + 1]);
+            if (fr) {
+                if (n_obs < O) { obs[2 * n_obs] = x; obs[2 * n_obs + 1] = y; }
+                n_obs++;
+            }
+        }
+    o.n_obs[n] = n_obs;  // > O is reported to the caller (the reference's buffer would not fit it either)
+    draw_target(W, H, infl.data(), rg.py, o.target + 2 * n);
+    // init_defender (base_env.py:72-120)
+    double *def = o.def + (size_t)n * P * 4;
+    std::vector<int> cells;
+    int placed = 0;
+    while (placed < P) {
+        double px = rg.np.random_sample() * (double)(W - 1), py = rg.np.random_sample() * (double)(H - 1);
+        bool ok = false;
+        if (infl[py_round(px) * H + py_round(py)] == 0) {
+            if (placed == 0) {
+                ok = true;
+            } else {
+                int collision = 0, connectivity = 0;
+                for (int k = 0; k < placed; k++) {
+                    double d = norm2(px - def[k * 4], py - def[k * 4 + 1]);
+                    if (d < (double)R.prm.min_dist) collision++;
+                    if (d < c.def_comm_range) connectivity++;
+                }
+                ok = collision == 0 && connectivity > 0 && connectivity <= 2;
+            }
+        }
+        if (ok) {
+            def[placed * 4] = px; def[placed * 4 + 1] = py; def[placed * 4 + 2] = 0.0; def[placed * 4 + 3] = 0.0;
+            placed++;
+            int cxi = py_round(px), cyi = py_round(py);
+            infl[cxi * H + cyi] = 1;
+            bool seen = false;
+            for (size_t k = 0; k < cells.size(); k += 2) seen = seen || (cells[k] == cxi && cells[k + 1] == cyi);
+            if (!seen) { cells.push_back(cxi); cells.push_back(cyi); }
+            for (size_t k = 0; k < cells.size(); k += 2) inflate(W, H, infl.data(), cells[k], cells[k + 1], 2);
+        }
+    }
+    // init_attacker (base_env.py:122-162), is_percepted=True
+    double *eva = o.eva + (size_t)n * 4;
+    for (bool done = false; !done;) {
+        double px = rg.np.random_sample() * (double)(W - 1), py = rg.np.random_sample() * (double)(H - 1);
+        if (infl[py_round(px) * H + py_round(py)] != 0) continue;
+        for (size_t k = 0; k < cells.size(); k += 2)
+            if (norm2((double)cells[k] - px, (double)cells[k + 1] - py) < c.def_sen_range) {
+                eva[0] = px; eva[1] = py; eva[2] = 0.0; eva[3] = 0.0;
+                done = true;
+                break;
+            }
+    }
+    // target tape: what init_target would return on the evader's next arrivals (pursuit_env.py:98-100)
+    rg.py_before_tape = rg.py;
+    rg.has_tape = true;
+    int32_t *tape = o.tape + (size_t)n * c.tape_len * 2;
+    for (int k = 0; k < c.tape_len; k++) draw_target(W, H, infl_static, rg.py, tape + 2 * k);
+}
+
+}  // namespace
+
+extern "C" {
+
+void *pe_resetter_create(const pe_config *cfg, const pe_reset_params *prm, int32_t N, const uint64_t *seeds) {
+    if (!cfg || !prm || !seeds || N < 1 || pe_config_check(cfg) != 0) return nullptr;
+    Resetter *R = new Resetter();
+    R->cfg = *cfg;
+    R->prm = *prm;
+    R->N = N;
+    R->rng.resize(N);
+    R->inflated.assign((size_t)N * cfg->W * cfg->H, 0);
+    for (int n = 0; n < N; n++) {
+        R->rng[n].py.seed(seeds[n]);
+        R->rng[n].np.seed((uint32_t)seeds[n]);
+    }
+    return R;
+}
+
+void pe_resetter_destroy(void *h) { delete (Resetter *)h; }
+
+int pe_resetter_reset(void *h, const int32_t *consumed_targets, const pe_host_init_out *out, int32_t n_threads) {
+    if (!h || !out) return PE_ERR_NULL;
+    Resetter &R = *(Resetter *)h;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > R.N) n_threads = R.N;
+    auto work = [&](int t) {
+        for (int n = t; n < R.N; n += n_threads) reset_one(R, n, consumed_targets ? consumed_targets[n] : 0, *out);
+    };
+    if (n_threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    return 0;
+}
+
+}  // extern "C"

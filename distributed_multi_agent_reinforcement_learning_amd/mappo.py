@@ -1,0 +1,302 @@
+"""MAPPO agent: batched on-device rollout, GAE, PPO-clip / value-clip update -- the reference's `MAPPO` API.
+
+Mirrors (reference paths) DHGN/mappo_parallel.py:548-831 `MAPPO` and DHGN/replay_buffer.py:5-99.  Differences that
+are design, not behaviour: rollouts of N environments advance in lockstep on the GPU (env tick = one fused HIP
+launch, policy = batched torch + fused HIP ops), transitions are written straight into device-resident
+(N, T, ...) buffers, the static obstacle list is stored once per episode instead of T times.  The reference's
+quirks that change numbers are reproduced when `runtime.reference_quirks` is true (default): the history list
+shared by actor and critic during rollouts and the critic's all-ones adjacency over padded obstacle
+slots in training only (Q5).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .model import build_actor_critic
+
+BUFFER_KEYS = ("p_state", "e_state", "o_state", "p_adj", "e_adj", "o_adj", "actor_historical_embedding",
+               "critic_historical_embedding", "v_n", "a_n", "a_logprob_n", "r", "active")
+
+
+class ReplayBuffer:
+    """Zero-padded episode buffer with the reference's keys and (N, T, ...) layouts (DHGN/replay_buffer.py:24-40),
+    resident in HBM.  `o_state` is stored once per episode as (N, O, 4) (`o_static`) and exposed in the reference's
+    (N, T, O, 4) shape as a broadcast view."""
+
+    def __init__(self, cfg, num_rows=None, device=None):
+        self.episode_limit = cfg.env.max_steps
+        self.batch_size = int(num_rows if num_rows is not None else cfg.algo.sample_epi_num)
+        self.device = torch.device(device if device is not None else cfg.algo.worker_device)
+        self.max_p_num, self.max_e_num, self.max_o_num = cfg.env.num_defender, cfg.env.num_attacker, cfg.map.num_max_obstacle
+        self.p_dim = self.e_dim = self.o_dim = cfg.env.state_dim
+        self.embedding_size = cfg.algo.embedding_dim
+        self.depth = cfg.algo.depth
+        self.buffer = None
+
+    def reset_buffer(self):
+        N, T, P, O, E, d = self.batch_size, self.episode_limit, self.max_p_num, self.max_o_num, self.embedding_size, self.depth
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
+        b = dict()
+        b["p_state"] = z(N, T, P, self.p_dim)
+        b["e_state"] = z(N, T, self.max_e_num, self.e_dim)
+        b["p_adj"] = z(N, T, P, P)
+        b["e_adj"] = z(N, T, P, self.max_e_num)
+        b["o_adj"] = z(N, T, P, O)
+        b["actor_historical_embedding"] = z(N, T + d, P, E)
+        b["critic_historical_embedding"] = z(N, T + d, P, E)
+        b["v_n"] = z(N, T + 1, P)
+        b["a_n"] = z(N, T, P)
+        b["a_logprob_n"] = z(N, T, P)
+        b["r"] = z(N, T, P)
+        b["active"] = z(N, T, P)
+        self.o_static = z(N, O, self.o_dim)
+        self.o_kvalid = torch.zeros(N, dtype=torch.int32, device=self.device)
+        b["o_state"] = self.o_static[:, None].expand(N, T, O, self.o_dim)
+        self.buffer = b
+        return self
+
+    @classmethod
+    def from_tensors(cls, cfg, tensors, o_kvalid=None, device=None):
+        """Builds a buffer from reference-layout tensors (e.g. golden fixtures); o_state (N,T,O,4) is static over T."""
+        N = tensors["r"].shape[0]
+        rb = cls(cfg, N, device).reset_buffer()
+        for k in BUFFER_KEYS:
+            if k == "o_state":
+                rb.o_static.copy_(tensors[k][:, 0])
+            else:
+                rb.buffer[k].copy_(tensors[k])
+        if o_kvalid is not None:
+            rb.o_kvalid.copy_(torch.as_tensor(o_kvalid, dtype=torch.int32))
+        return rb
+
+
+class BigBuffer:
+    """Learner-side concatenation of worker buffers (DHGN/replay_buffer.py:68-99)."""
+
+    def __init__(self):
+        self.buffer = None
+        self.o_static = None
+
+    def reset(self):
+        self.buffer = None
+        self.o_static = None
+
+    def concat_buffer(self, mini_buffer):
+        if self.buffer is None:
+            self.buffer = dict(mini_buffer.buffer)
+            self.o_static = mini_buffer.o_static
+        else:
+            self.o_static = torch.cat([self.o_static, mini_buffer.o_static], dim=0)
+            for key in self.buffer:
+                if key != "o_state":
+                    self.buffer[key] = torch.cat([self.buffer[key], mini_buffer.buffer[key]], dim=0)
+            N, T = self.buffer["r"].shape[:2]
+            self.buffer["o_state"] = self.o_static[:, None].expand(N, T, *self.o_static.shape[1:])
+
+    def get_training_data(self, device):
+        device = torch.device(device)
+        if self.o_static.device != device:
+            self.o_static = self.o_static.to(device)
+            for key in self.buffer:
+                if key != "o_state":
+                    self.buffer[key] = self.buffer[key].to(device)
+            N, T = self.buffer["r"].shape[:2]
+            self.buffer["o_state"] = self.o_static[:, None].expand(N, T, *self.o_static.shape[1:])
+        return self.buffer
+
+
+class MAPPO:
+    def __init__(self, cfg, batch_size, mini_batch_size, agent_type):
+        self.batch_size = batch_size
+        self.mini_batch_size = mini_batch_size
+        a = cfg.algo
+        self.max_train_steps, self.lr, self.gamma, self.lamda = a.max_train_steps, a.lr, a.gamma, a.lamda
+        self.epsilon, self.K_epochs, self.entropy_coef = a.epsilon, a.epochs, a.entropy_coef
+        self.use_grad_clip, self.use_lr_decay = a.use_grad_clip, a.use_lr_decay
+        self.use_adv_norm, self.use_value_clip = a.use_adv_norm, a.use_value_clip
+        self.action_dim, self.input_dim = cfg.env.action_dim, cfg.env.state_dim
+        self.num_layers, self.embedding_dim = a.num_layers, a.embedding_dim
+        self.rnn_input_dim, self.rnn_hidden_dim = a.embedding_dim, a.rnn_hidden_dim
+        self.sn = a.use_spectral_norm
+        key = "learner_device" if "Learner" in agent_type else ("worker_device" if "Worker" in agent_type else "evaluator_device")
+        self.device = torch.device(getattr(a, key))
+        if self.device.type != "cuda":
+            raise RuntimeError(f"algo.{key}={getattr(a, key)!r}: this MAPPO runs on the GPU only (HIP kernels, no CPU fallback)")
+        self.depth = a.depth
+        self.actor, self.critic = build_actor_critic(cfg, self.device)
+        enc = self.actor.shared_net
+        # same parameter order as the reference's ac_parameters (:631): Adam state / clip_grad_norm_ follow it
+        self.ac_parameters = (list(enc.parameters()) + list(self.actor.GRU.parameters()) + list(self.critic.GRU.parameters())
+                              + list(self.critic.Mean.parameters()) + list(self.actor.Mean.parameters()))
+        self.ac_optimizer = torch.optim.Adam(self.ac_parameters, lr=self.lr, eps=1e-5)
+        self.minibuffer = None
+        self.total_step = 0
+        self.cfg = cfg
+        rt = cfg.get("runtime", {})
+        self.reference_quirks = bool(rt.get("reference_quirks", True))
+        self.sample_seed = int(rt.get("seed", 0))
+        self.sample_offset = 0
+        self.last_adv = self.last_v_target = None
+
+    # ---- update (:638-723) ------------------------------------------------------------------------------------
+    def train(self, replay_buffer, total_steps, return_grads=True):
+        batch = replay_buffer.get_training_data(self.device) if hasattr(replay_buffer, "get_training_data") else replay_buffer.buffer
+        o_static = replay_buffer.o_static
+        N, T, P = batch["r"].shape
+        if N != self.batch_size:
+            raise ValueError(f"buffer holds {N} episodes, MAPPO was built for batch_size={self.batch_size}")
+        with torch.no_grad():
+            adv, v_target = ops.gae_advnorm(batch["r"], batch["v_n"], batch["active"], self.gamma, self.lamda, self.use_adv_norm)
+        self.last_adv, self.last_v_target = adv, v_target
+        object_critics = object_actors = 0.0
+        update_time = 0
+        self.ac_optimizer.zero_grad()
+        d = self.depth
+        for n0 in range(0, N, self.mini_batch_size):  # BatchSampler(SequentialSampler, mini_batch_size, drop_last=False)
+            n1 = min(n0 + self.mini_batch_size, N)
+            mb = n1 - n0
+            R = mb * T
+            obs = dict(p_state=batch["p_state"][n0:n1].reshape(R, P, -1), e_state=batch["e_state"][n0:n1].reshape(R, 1, -1),
+                       o_state=o_static[n0:n1], q_div=T, p_adj=batch["p_adj"][n0:n1].reshape(R, P, P),
+                       e_adj=batch["e_adj"][n0:n1].reshape(R, P, 1), o_adj=batch["o_adj"][n0:n1].reshape(R, P, -1))
+            # EmbeddingDataset2 (:95-113): hop k reads the stored embeddings of step t-1-k (clean per-net history)
+            hist_a = [batch["actor_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
+            hist_c = [batch["critic_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
+            a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
+            values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
+            active = batch["active"][n0:n1]
+            ratios = torch.exp(a_logprob_n_now - batch["a_logprob_n"][n0:n1].detach())
+            surr1 = ratios * adv[n0:n1]
+            surr2 = torch.clamp(ratios, 1 - self.epsilon, 1 + self.epsilon) * adv[n0:n1]
+            actor_loss = -torch.min(surr1, surr2) - self.entropy_coef * dist_entropy
+            actor_loss = (actor_loss * active).sum() / active.sum()
+            if self.use_value_clip:
+                values_old = batch["v_n"][n0:n1, :-1].detach()
+                err_clip = torch.clamp(values_now - values_old, -self.epsilon, self.epsilon) + values_old - v_target[n0:n1]
+                err_orig = values_now - v_target[n0:n1]
+                critic_loss = torch.max(err_clip ** 2, err_orig ** 2)
+            else:
+                critic_loss = (values_now - v_target[n0:n1]) ** 2
+            critic_loss = (critic_loss * active).sum() / active.sum()
+            (actor_loss + critic_loss).backward()
+            if self.use_grad_clip:  # on the gradients accumulated so far, after every mini-batch
+                torch.nn.utils.clip_grad_norm_(self.ac_parameters, 5.0)
+            object_critics += critic_loss.item()
+            object_actors += actor_loss.item()
+            update_time += 1
+        if self.use_lr_decay:
+            self.lr_decay(total_steps)
+        if not return_grads:  # device-side path: gradients stay in .grad for the flat all-reduce
+            return object_critics / update_time, object_actors / update_time, None, None
+        return object_critics / update_time, object_actors / update_time, self.actor.get_gradients(), self.critic.get_gradients()
+
+    def lr_decay(self, total_steps):
+        lr_now = self.lr * (1 - total_steps / self.max_train_steps)
+        for p in self.ac_optimizer.param_groups:
+            p["lr"] = lr_now
+        self.total_step = total_steps
+
+    # ---- gradient transport on the device (replaces the numpy lists of main.py:105-129) ---------------------
+    def flat_grads(self):
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.ac_parameters])
+
+    def set_flat_grads(self, flat):
+        o = 0
+        for p in self.ac_parameters:
+            n = p.numel()
+            p.grad = flat[o:o + n].view_as(p).clone()
+            o += n
+
+    # ---- rollout (:731-827) -----------------------------------------------------------------------------------
+    def explore_env(self, env, num_episode, actions_override=None, init=None):
+        N = env.num_envs
+        self.minibuffer = ReplayBuffer(self.cfg, N * num_episode, self.device).reset_buffer()
+        exp_reward = 0.0
+        sample_steps = 0
+        for k in range(num_episode):
+            ep_reward, ep_steps = self.run_episode(env, num_episode=k, actions_override=actions_override, init=init)
+            exp_reward += float(ep_reward.mean().item())
+            sample_steps += ep_steps * N
+        return exp_reward / num_episode, self.minibuffer, sample_steps
+
+    @torch.no_grad()
+    def run_episode(self, env, num_episode=0, actions_override=None, init=None):
+        """N episodes in lockstep; rows [num_episode*N, (num_episode+1)*N) of the buffer.  Returns the per-environment
+        episode reward (N,) and the episode length."""
+        N, P, T, d = env.num_envs, env.num_defender, env.max_steps, self.depth
+        L, H, E = self.num_layers, self.rnn_hidden_dim, self.embedding_dim
+        dev = self.device
+        buf = self.minibuffer.buffer
+        rows = slice(num_episode * N, (num_episode + 1) * N)
+        env.reset(init)
+        self.minibuffer.o_static[rows].copy_(env.boundary_map.obstacle_agent)
+        self.minibuffer.o_kvalid[rows].copy_(env.n_obs)
+        o_state, o_kvalid = self.minibuffer.o_static[rows], self.minibuffer.o_kvalid[rows]
+        ha = torch.zeros(L, N * P, H, device=dev)
+        hc = torch.zeros(L, N * P, H, device=dev)
+        shared = [torch.zeros(N, P, E, device=dev) for _ in range(d)]
+        a_hist = list(shared)
+        c_hist = list(shared)
+        a_cur = torch.zeros(N, P, E, device=dev)
+        c_cur = torch.zeros(N, P, E, device=dev)
+        episode_reward = torch.zeros(N, device=dev)
+        raw = torch.zeros(N, P, device=dev)
+
+        def obs_views(t):
+            return {k: buf[k][rows, t] for k in ("p_state", "e_state", "p_adj", "e_adj", "o_adj")}
+
+        env.observe(obs_views(0))
+        env.attacker_step()
+        for t in range(T):
+            o = obs_views(t)
+            o["o_state"] = o_state
+            o["o_kvalid"] = o_kvalid
+            if d:
+                if self.reference_quirks:  # one list serves both nets: (.., a_{t-1}, c_{t-1})
+                    shared = (shared + [a_cur, c_cur])[-d:]
+                    hops_a = hops_c = [shared[d - 1 - k] for k in range(d)]
+                else:
+                    a_hist = (a_hist + [a_cur])[-d:]
+                    c_hist = (c_hist + [c_cur])[-d:]
+                    hops_a = [a_hist[d - 1 - k] for k in range(d)]
+                    hops_c = [c_hist[d - 1 - k] for k in range(d)]
+            else:
+                hops_a = hops_c = []
+            prob, ha, a_cur = self.actor(o, hops_a, ha, 0)
+            v_n, hc, c_cur = self.critic(o, hops_c, hc, 0, rollout=True)
+            if actions_override is not None:
+                a_n = actions_override[rows, t].to(dev).long()
+                a_logprob = torch.distributions.Categorical(probs=prob).log_prob(a_n)
+                a_n = a_n.to(torch.int32)
+            else:
+                a_n, a_logprob = ops.categorical_sample(prob, self.sample_seed, self.sample_offset)
+                self.sample_offset += N * P
+            buf["actor_historical_embedding"][rows, t + d] = a_cur
+            buf["critic_historical_embedding"][rows, t + d] = c_cur
+            buf["v_n"][rows, t] = v_n.reshape(N, P)
+            buf["a_n"][rows, t] = a_n.float()
+            buf["a_logprob_n"][rows, t] = a_logprob
+            buf["active"][rows, t] = 1.0
+            if t + 1 < T:
+                env.tick(a_n, obs_views(t + 1), buf["r"][rows, t], raw)
+            else:
+                env.sim.step(a_n, buf["r"][rows, t], raw)
+                env.time_step += 1
+            episode_reward += raw.sum(-1)
+        # bootstrap value of the state after the last step (:807-825): only the critic's embedding enters the history
+        fin = env.observe()
+        fin["o_state"], fin["o_kvalid"] = o_state, o_kvalid
+        if d:
+            if self.reference_quirks:
+                shared = (shared + [c_cur])[-d:]
+                hops_c = [shared[d - 1 - k] for k in range(d)]
+            else:
+                c_hist = (c_hist + [c_cur])[-d:]
+                hops_c = [c_hist[d - 1 - k] for k in range(d)]
+        v_n, hc, c_cur = self.critic(fin, hops_c, hc, 0, rollout=True)
+        buf["v_n"][rows, T] = v_n.reshape(N, P)
+        return episode_reward, T
+
+    def save_model(self, cwd):
+        torch.save(self.actor.state_dict(), cwd + "actor.pth")
+        torch.save(self.critic.state_dict(), cwd + "critic.pth")

@@ -30,8 +30,8 @@ def load_library():
                                "the fused MAPPO ops have no fallback")
         L = C.CDLL(path)
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-        L.dhgn_msg_agg_fwd.argtypes = [i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
-        L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.dhgn_msg_agg_fwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp]
+        L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
         L.dhgn_msg_agg_bwd_workspace.restype = i64
         L.gae_advnorm.argtypes = [i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
@@ -60,6 +60,11 @@ def _need_gpu(t, name):
         raise RuntimeError(f"{name}: tensor is on {t.device}; the fused HIP ops run on the GPU only (no CPU fallback)")
 
 
+def _rows_ok(t):
+    """each row (dim 0) is a dense block; rows may be strided (a slice buffer[:, t] of an (N, T, ...) tensor)"""
+    return t[0].is_contiguous() and (t.shape[0] == 1 or t.stride(0) >= t[0].numel())
+
+
 _workspaces = {}
 
 
@@ -81,18 +86,20 @@ class _MsgAgg(torch.autograd.Function):
         R, P = p.shape[0], p.shape[1]
         K = q.shape[1]
         E, din = W.shape
-        assert p.dtype == torch.float32 and p.is_contiguous() and p.shape[2] == 4
-        assert q.is_contiguous() and q.shape[2] == 4 and q.shape[0] * q_div == R
+        assert p.dtype == torch.float32 and p.shape[2] == 4 and _rows_ok(p)
+        assert _rows_ok(q) and q.shape[2] == 4 and q.shape[0] * q_div == R and q.stride(0) % 4 == 0
         if adj is not None:
-            assert adj.is_contiguous() and adj.shape == (R, P, K) and adj.dtype == torch.float32
+            assert adj.shape == (R, P, K) and adj.dtype == torch.float32 and _rows_ok(adj)
         if e is not None:
-            assert e.is_contiguous() and e.shape == (R, 4)
+            assert e.shape == (R, 4) and _rows_ok(e)
+        ctx.strides = (p.stride(0), q.stride(0), e.stride(0) if e is not None else 0, adj.stride(0) if adj is not None else 0)
         if kvalid is not None:
             assert kvalid.dtype == torch.int32 and kvalid.is_contiguous() and kvalid.shape[0] * q_div == R
         Wc, bc = W.detach().contiguous(), b.detach().contiguous()
         out = torch.empty((R, P, E), dtype=torch.float32, device=p.device)
-        _check(L.dhgn_msg_agg_fwd(R, P, K, E, din, _ptr(p), _ptr(q), q_div, _ptr(e), _ptr(adj), adj_mode, _ptr(kvalid),
-                                  _ptr(Wc), _ptr(bc), _ptr(out), _stream()), "dhgn_msg_agg_fwd")
+        ps, qs, es, as_ = ctx.strides
+        _check(L.dhgn_msg_agg_fwd(R, P, K, E, din, _ptr(p), ps, _ptr(q), qs, q_div, _ptr(e), es, _ptr(adj), as_, adj_mode,
+                                  _ptr(kvalid), _ptr(Wc), _ptr(bc), _ptr(out), _stream()), "dhgn_msg_agg_fwd")
         ctx.save_for_backward(p, q, e, adj, kvalid, Wc, bc)
         ctx.meta = (adj_mode, q_div)
         return out
@@ -109,8 +116,10 @@ class _MsgAgg(torch.autograd.Function):
         dW = torch.empty_like(W)
         db = torch.empty_like(b)
         ws = _workspace(p.device, E, din)
-        _check(L.dhgn_msg_agg_bwd(R, P, K, E, din, _ptr(p), _ptr(q), q_div, _ptr(e), _ptr(adj), adj_mode, _ptr(kvalid), _ptr(W),
-                                  _ptr(b), _ptr(gout), _ptr(dW), _ptr(db), _ptr(ws), _stream()), "dhgn_msg_agg_bwd")
+        ps, qs, es, as_ = ctx.strides
+        _check(L.dhgn_msg_agg_bwd(R, P, K, E, din, _ptr(p), ps, _ptr(q), qs, q_div, _ptr(e), es, _ptr(adj), as_, adj_mode,
+                                  _ptr(kvalid), _ptr(W), _ptr(b), _ptr(gout), _ptr(dW), _ptr(db), _ptr(ws), _stream()),
+               "dhgn_msg_agg_bwd")
         return None, None, None, None, None, dW, db, None, None
 
 

@@ -48,6 +48,14 @@ class PeHostInit(C.Structure):
                [("reset_rn", C.c_int32), ("pad0", C.c_int32)]
 
 
+class PeResetParams(C.Structure):
+    _fields_ = [("num_blocks", C.c_int32), ("min_dist", C.c_int32), ("center", C.c_double * 2), ("variance", C.c_double)]
+
+
+class PeHostInitOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("grid", "obs_xy", "n_obs", "def_", "eva", "target", "tape")]
+
+
 EXPORTS = ("pe_config_check", "pe_tick_lds_bytes", "pe_env_load", "pe_env_observe", "pe_evader_step", "pe_env_step",
            "pe_env_tick", "pe_astar_batch", "pe_error_string")
 
@@ -78,6 +86,10 @@ def load_library():
         L.pe_env_tick.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
         L.pe_astar_batch.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]
         L.pe_diag_norm2.argtypes = [C.c_int32, vp, vp, vp, vp]
+        L.pe_resetter_create.argtypes = [vp, vp, C.c_int32, vp]
+        L.pe_resetter_create.restype = vp
+        L.pe_resetter_destroy.argtypes = [vp]
+        L.pe_resetter_reset.argtypes = [vp, vp, vp, C.c_int32]
         L.pe_error_string.argtypes = [C.c_int]
         L.pe_error_string.restype = C.c_char_p
         _lib = L
@@ -282,3 +294,50 @@ def astar_batch(W, H, obs, sg, max_path=256):
     _check(L.pe_astar_batch(W, H, n, _ptr(obs_d), _ptr(sg_d), _ptr(path), _ptr(lens), max_path, _stream()), "pe_astar_batch")
     torch.cuda.synchronize()
     return path.cpu().numpy(), lens.cpu().numpy()
+
+
+class HostResetter:
+    """Host side of Pursuit_Env.reset() for N environments (csrc/pe_reset.cpp): per-environment re-implementations of
+    the reference's `random` / `numpy.random` streams, seeded like random.seed(s); np.random.seed(s)."""
+
+    def __init__(self, pe_cfg: PeConfig, cfg, seeds, n_threads=None):
+        self.L = load_library()
+        self.c = pe_cfg
+        self.N = len(seeds)
+        prm = PeResetParams()
+        prm.num_blocks = int(cfg.map.num_obstacle_block)
+        prm.min_dist = 4  # pursuit_env.py:71
+        prm.center[0], prm.center[1] = float(cfg.map.center[0]), float(cfg.map.center[1])
+        prm.variance = float(cfg.map.variance)
+        s = np.ascontiguousarray(seeds, np.uint64)
+        if (s >> np.uint64(32)).any():
+            raise ValueError("seeds must fit 32 bits (numpy.random.seed range)")
+        self.h = self.L.pe_resetter_create(C.byref(pe_cfg), C.byref(prm), self.N, _np(s))
+        if not self.h:
+            raise RuntimeError("pe_resetter_create failed (bad configuration)")
+        self.n_threads = int(n_threads or min(16, os.cpu_count() or 1))
+        self.first = True
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.pe_resetter_destroy(self.h)
+        except Exception:
+            pass
+
+    def reset(self, consumed_targets=None):
+        c, N = self.c, self.N
+        out = dict(grid=np.empty((N, c.W, c.H), np.uint8), obs_xy=np.empty((N, c.O, 2), np.int32), n_obs=np.empty(N, np.int32),
+                   defenders=np.empty((N, c.P, 4), np.float64), evader=np.empty((N, 4), np.float64),
+                   target=np.empty((N, 2), np.int32), tape=np.empty((N, c.tape_len, 2), np.int32))
+        o = PeHostInitOut()
+        o.grid, o.obs_xy, o.n_obs, o.def_, o.eva, o.target, o.tape = (_np(out[k]) for k in
+                                                                        ("grid", "obs_xy", "n_obs", "defenders", "evader", "target", "tape"))
+        ct = None
+        if not self.first:
+            if consumed_targets is None:
+                raise ValueError("consumed_targets (tape positions of the finished episode) is required after the first reset")
+            ct = np.ascontiguousarray(consumed_targets, np.int32)
+        _check(self.L.pe_resetter_reset(self.h, _np(ct) if ct is not None else None, C.byref(o), self.n_threads), "pe_resetter_reset")
+        self.first = False
+        return out

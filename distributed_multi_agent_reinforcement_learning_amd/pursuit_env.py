@@ -1,0 +1,125 @@
+"""`Pursuit_Env`: the reference's environment API on top of the batched HIP simulator.
+
+Mirrors environment/pursuit_evasion_game/pursuit_env.py:56-229 (+ base_env.py) of the reference for `num_envs`
+independent environments at once: every method keeps the reference's name and meaning, tensors carry a leading
+environment dimension N (one reference `Worker` each).  The simulation runs in csrc/pe_env.hip through the C ABI of
+include/pe_env.h; the episode reset runs in csrc/pe_reset.cpp with per-environment replicas of the reference's RNG
+streams (environment n of rank r is seeded `seed + 1000 * r + n`).
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import pe_env
+
+
+class Pursuit_Env:
+    def __init__(self, cfg, num_envs=None, rank=0, device=None, seeds=None):
+        self.cfg = cfg
+        rt = cfg.get("runtime", {}) if hasattr(cfg, "get") else {}
+        self.num_envs = int(num_envs if num_envs is not None else rt.get("num_envs", 1))
+        self.device = torch.device(device if device is not None else "cuda")
+        self.map_config, self.env_config = cfg.map, cfg.env
+        self.defender_config, self.attacker_config, self.sensor_config = cfg.defender, cfg.attacker, cfg.sensor
+        self.max_steps = cfg.env.max_steps
+        self.step_size = cfg.env.step_size
+        self.num_target, self.num_defender, self.num_attacker = cfg.env.num_target, cfg.env.num_defender, cfg.env.num_attacker
+        self.time_step = 0
+        self.n_episode = 0
+        self.pe_cfg = pe_env.make_pe_config(cfg, tape_len=int(rt.get("tape_len", 16)), max_path=int(rt.get("max_path", 128)))
+        self.sim = pe_env.BatchedEnv(self.pe_cfg, self.num_envs, self.device)
+        if seeds is None:
+            base = int(rt.get("seed", 0)) + 1000 * int(rank)
+            seeds = [base + n for n in range(self.num_envs)]
+        self.seeds = list(seeds)
+        self.resetter = pe_env.HostResetter(self.pe_cfg, cfg, self.seeds)
+        self.boundary_map = SimpleNamespace(obstacle_agent=self.sim.o_state)  # (N, O, 4) [x, y, 0, 0], zero padded
+        self._obs = None
+        self._reward = torch.zeros((self.num_envs, self.num_defender), dtype=torch.float32, device=self.device)
+        self._raw = torch.zeros_like(self._reward)
+        self._done = torch.zeros((self.num_envs,), dtype=torch.uint8, device=self.device)
+
+    # ---- reference API -------------------------------------------------------------------------------------
+    def reset(self, init=None):
+        """pursuit_env.py:60-73.  `init` (host arrays, see BatchedEnv.load) injects recorded initial conditions."""
+        self.time_step = 0
+        self.n_episode += 1
+        if init is None:
+            consumed = None if self.resetter.first else self.sim.meta[:, pe_env.META_TAPE_POS].cpu().numpy()
+            init = self.resetter.reset(consumed)
+        self.sim.load(init)
+        self.last_init = init
+        return None
+
+    @property
+    def collision(self):
+        return self.sim.meta[:, pe_env.META_COLLISION].bool()
+
+    @property
+    def target(self):
+        return self.sim.target
+
+    @property
+    def n_obs(self):
+        return self.sim.n_obs
+
+    def get_state(self, agent_type):
+        """base_env.py:198-209: (N, P, 4) defenders or (N, 1, 4) attacker, f64 [x, y, vx, vy]."""
+        if agent_type == "defender":
+            return self.sim.defenders_aos()
+        if agent_type == "attacker":
+            return self.sim.eva.unsqueeze(1)
+        raise KeyError(agent_type)
+
+    def observe(self, obs=None):
+        """get_state + communicate + sensor in one launch; fp32 tensors in the reference's layouts."""
+        self._obs = self.sim.observe(obs)
+        return self._obs
+
+    def communicate(self):
+        """pursuit_env.py:182-195 -> (N, P, P) fp32"""
+        return self.observe()["p_adj"]
+
+    def sensor(self):
+        """pursuit_env.py:197-209 -> (o_adj (N, P, O), e_adj (N, P, 1))"""
+        o = self.observe()
+        return o["o_adj"], o["e_adj"]
+
+    def attacker_step(self):
+        """pursuit_env.py:75-102 (replan every `difficulty` steps, follow the path, re-draw the target on arrival)."""
+        self.sim.evader_step()
+        return None
+
+    def step(self, action):
+        """pursuit_env.py:104-123 -> (rewards (N, P) raw fp32, done, info)"""
+        a = torch.as_tensor(action, device=self.device)
+        self.sim.step(a.reshape(self.num_envs, self.num_defender), self._reward, self._raw, self._done)
+        self.time_step += 1
+        return self._raw, self.time_step >= self.max_steps, None
+
+    def demon(self):
+        """pursuit_env.py:211-229: scripted pursuit, the discrete action closest to the bearing of the evader."""
+        d = self.sim.defenders_aos()
+        e = self.sim.eva
+        dx, dy = e[:, None, 0] - d[:, :, 0], e[:, None, 1] - d[:, :, 1]
+        radius = torch.sqrt(dx * dx + dy * dy)
+        phi = torch.sign(dy) * torch.arccos(dx / (radius + 1e-3))
+        ax, ay = torch.cos(phi), torch.sin(phi)
+        still = radius <= 0.01
+        ax = torch.where(still, torch.zeros_like(ax), ax)
+        ay = torch.where(still, torch.zeros_like(ay), ay)
+        th = torch.tensor([i * math.pi / 4 for i in range(8)], dtype=torch.float64, device=self.device)
+        tab = torch.stack((torch.cat((torch.cos(th), th.new_zeros(1))), torch.cat((torch.sin(th), th.new_zeros(1)))), -1)
+        dist = torch.sqrt((tab[None, None, :, 0] - ax[..., None]) ** 2 + (tab[None, None, :, 1] - ay[..., None]) ** 2)
+        return dist.argmin(-1)
+
+    def get_done(self):
+        return self.time_step >= self.max_steps
+
+    # ---- fused rollout entry (one launch per environment tick) ---------------------------------------------
+    def tick(self, action, obs, reward, reward_raw=None, done=None):
+        """step(action) -> observe -> attacker_step fused (the tail of one run_episode iteration and the head of the next)."""
+        self.sim.tick(action, obs, reward, reward_raw, done)
+        self.time_step += 1

@@ -1,0 +1,139 @@
+"""Data-parallel MAPPO training loop: one process per GPU, environment shards per rank, one RCCL all-reduce per epoch.
+
+Same protocol as the reference's driver (main.py:41-172): rollouts -> per-learner GAE with its own advantage
+normalisation -> gradient SUM over learners -> the same Adam step everywhere -> evaluation / checkpoints.  What was a
+parameter-server sum of numpy lists through the Ray object store (main.py:105-129) is one `all_reduce(SUM)` of a
+single flat fp32 bucket (~0.6 M elements) over xGMI; weights are never re-broadcast because every rank applies the
+identical update.  Rollout data never leaves the GPU that produced it.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .evaluator import EvaluatorProc, draw_learning_curve
+from .mappo import MAPPO
+from .pursuit_env import Pursuit_Env
+
+
+def dist_env():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed(backend=None):
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def allreduce_sum_(flat):
+    """gradient SUM over learners (main.py:121-126); no-op on one rank"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def broadcast_weights_(modules, src=0):
+    """initial weight sync from learner 0 (main.py:73-75)"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        seen = set()
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    dist.broadcast(t.data, src=src)
+
+
+def save_checkpoint(actor, critic, cwd, suffix=""):
+    """main.py:146-172: eight whole-module files; plus state_dicts (loadable without this package)."""
+    os.makedirs(cwd, exist_ok=True)
+    torch.save(actor, f"{cwd}/actor{suffix}.pth")
+    torch.save(critic, f"{cwd}/critic{suffix}.pth")
+    torch.save(actor.shared_net, f"{cwd}/actor_gnn{suffix}.pth")
+    torch.save(critic.shared_net, f"{cwd}/critic_gnn{suffix}.pth")
+    torch.save(actor.GRU, f"{cwd}/actor_gru{suffix}.pth")
+    torch.save(critic.GRU, f"{cwd}/critic_gru{suffix}.pth")
+    torch.save(actor.Mean, f"{cwd}/actor_mean{suffix}.pth")
+    torch.save(critic.Mean, f"{cwd}/critic_mean{suffix}.pth")
+    torch.save({"actor": actor.state_dict(), "critic": critic.state_dict()}, f"{cwd}/state_dicts{suffix}.pt")
+
+
+class Trainer:
+    """One rank of the data-parallel job."""
+
+    def __init__(self, cfg, num_envs=None, mini_batch_size=None):
+        self.rank, self.local_rank, self.world = init_distributed()
+        self.cfg = cfg
+        self.device = torch.device("cuda", self.local_rank if torch.cuda.device_count() > 1 else 0)
+        torch.cuda.set_device(self.device)
+        self.num_envs = int(num_envs if num_envs is not None else cfg.runtime.num_envs)
+        epi = int(cfg.algo.sample_epi_num)
+        batch = self.num_envs * epi
+        # main.py:48: mini_batch_size = round(num_workers * sample_epi_num / 10)
+        self.mini_batch_size = int(mini_batch_size if mini_batch_size is not None else max(1, round(batch / 10)))
+        self.env = Pursuit_Env(cfg, num_envs=self.num_envs, rank=self.rank, device=self.device)
+        torch.manual_seed(int(cfg.runtime.get("seed", 0)))
+        self.agent = MAPPO(cfg, batch, self.mini_batch_size, "Learner")
+        broadcast_weights_([self.agent.actor, self.agent.critic])
+        self.total_steps = 0
+        self.iteration = 0
+        self.last_log = (0.0, 0.0)
+
+    def iterate(self):
+        """rollout + `epochs` updates; returns (env_steps_this_iteration_all_ranks, exp_reward)."""
+        cfg, agent = self.cfg, self.agent
+        exp_r, buffer, steps = agent.explore_env(self.env, int(cfg.algo.sample_epi_num))
+        self.total_steps += steps * self.world
+        for _ in range(int(cfg.algo.epochs)):
+            with torch.enable_grad():
+                obj_c, obj_a, _, _ = agent.train(buffer, self.total_steps, return_grads=False)
+            flat = allreduce_sum_(agent.flat_grads())
+            agent.set_flat_grads(flat)
+            agent.ac_optimizer.step()
+            if cfg.algo.use_lr_decay:
+                agent.lr_decay(self.total_steps)
+            self.last_log = (obj_c, obj_a)
+        self.iteration += 1
+        return steps * self.world, exp_r
+
+
+def train_agent_multiprocessing(cfg, max_iterations=None, num_eval_envs=16, eval_every=1):
+    """main.py:41-172 on the Trainer: runs until the evaluator says stop (total_step > max_train_steps)."""
+    tr = Trainer(cfg)
+    evaluator = EvaluatorProc(cfg, num_eval_envs) if tr.rank == 0 else None
+    cwd = cfg.algo.save_cwd
+    if_train = True
+    while if_train:
+        t0 = time.time()
+        steps, exp_r = tr.iterate()
+        if tr.rank == 0:
+            print(f"iteration {tr.iteration}: {steps} env-steps in {time.time() - t0:.2f}s")
+            if tr.iteration % eval_every == 0:
+                aw, cw = tr.agent.actor.get_weights(), tr.agent.critic.get_weights()
+                if_train, ref_list = evaluator.run(aw, cw, tr.total_steps, exp_r, tr.last_log)
+                if ref_list:
+                    actor, critic, recorder = ref_list
+                    os.makedirs(cwd, exist_ok=True)
+                    np.save(cwd + "/recorder.npy", recorder)
+                    draw_learning_curve(recorder=np.array(recorder), cwd=cwd)
+                    save_checkpoint(actor, critic, cwd)
+        if tr.world > 1:
+            flag = torch.tensor([1 if if_train else 0], device=tr.device)
+            dist.broadcast(flag, src=0)
+            if_train = bool(flag.item())
+        if max_iterations is not None and tr.iteration >= max_iterations:
+            break
+    if tr.rank == 0:
+        save_checkpoint(tr.agent.actor, tr.agent.critic, cwd, "_final")
+        np.save(cwd + "/recorder.npy", evaluator.get_recorder())
+    return tr

@@ -28,13 +28,15 @@ enum { MO_ADJ_TENSOR = 0,   /* actor: the observed adjacency                    
  * i.e. DHGN.coordinate + DHGN.message + the matmul of DHGN.mean_operator (DHGN/mappo_parallel.py:235-239,
  * 323-334, 346-347) for relation 0 (q = p, din = 8, e given), 1 (q = e, K = 1) and 2 (q = obstacles).
  *   R rows, P agents, K neighbours, E features (multiple of 64, <= 256), din in {4, 8};
- *   p [R][P][4]; q [R/q_div][K][4] (q_div p-rows share one q-row: obstacles are static over an episode);
+ *   p [R][P][4] (rows p_row_stride elements apart, likewise e and adj: rows may be slices buffer[:, t] of (N,T,..)
+ *   replay-buffer tensors); q [R/q_div][K][4] (q_div p-rows share one q-row: obstacles are static over an episode);
  *   e [R][4] or NULL (din == 4); adj [R][P][K] (MO_ADJ_TENSOR) ; kvalid [R/q_div] (MO_ADJ_VALID);
  *   W [E][din]; b [E]; out [R][P][E].
  */
-int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, const float *q, int32_t q_div,
-                     const float *e, const float *adj, int32_t adj_mode, const int32_t *kvalid, const float *W,
-                     const float *b, float *out, void *stream);
+int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_row_stride,
+                     const float *q, int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const float *adj,
+                     int64_t adj_row_stride, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
+                     float *out, void *stream);
 
 /*
  * Backward of the above w.r.t. W and b (the inputs are data, they carry no gradient): recomputes the
@@ -43,9 +45,10 @@ int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
  * workspace: at least dhgn_msg_agg_bwd_workspace(E, din) bytes.
  */
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din);
-int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, const float *q, int32_t q_div,
-                     const float *e, const float *adj, int32_t adj_mode, const int32_t *kvalid, const float *W,
-                     const float *b, const float *gout, float *dW, float *db, void *workspace, void *stream);
+int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_row_stride,
+                     const float *q, int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const float *adj,
+                     int64_t adj_row_stride, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
+                     const float *gout, float *dW, float *db, void *workspace, void *stream);
 
 /*
  * GAE reverse scan + value target + advantage normalisation (DHGN/mappo_parallel.py:643-658):

@@ -102,6 +102,29 @@ typedef struct pe_host_init {
     int32_t pad0;
 } pe_host_init;
 
+/* Map / placement parameters of Pursuit_Env.reset that are not needed on the device (config.yaml:30-36,
+ * pursuit_env.py:71 min_dist=4). */
+typedef struct pe_reset_params {
+    int32_t num_blocks;       /* map.num_obstacle_block */
+    int32_t min_dist;         /* defender spacing, 4 in the reference */
+    double center[2];         /* map.center   */
+    double variance;          /* map.variance */
+} pe_reset_params;
+
+/* HOST arrays the resetter fills; same shapes as pe_host_init. */
+typedef struct pe_host_init_out {
+    uint8_t *grid; int32_t *obs_xy; int32_t *n_obs; double *def; double *eva; int32_t *target; int32_t *tape;
+} pe_host_init_out;
+
+/* Host side of Pursuit_Env.reset() (pursuit_env.py:60-73, base_env.py:37-162, Occupied_Grid_Map.py:46-62) for N
+ * environments.  Environment n owns bit-exact re-implementations of the two generator streams the reference draws
+ * from (Python `random`, numpy legacy RandomState), seeded like random.seed(seeds[n]); np.random.seed(seeds[n]).
+ * consumed_targets[n] (may be NULL on the first call) = how many tape targets the evader used in the episode that
+ * just ended; the un-used draws are returned to the stream before the next reset. */
+void *pe_resetter_create(const pe_config *cfg, const pe_reset_params *prm, int32_t N, const uint64_t *seeds);
+void pe_resetter_destroy(void *resetter);
+int pe_resetter_reset(void *resetter, const int32_t *consumed_targets, const pe_host_init_out *out, int32_t n_threads);
+
 /* Validates a configuration against the kernels' limits. */
 int pe_config_check(const pe_config *cfg);
 /* Bytes of dynamic LDS one workgroup of the fused tick uses (for occupancy reports). */

@@ -37,7 +37,7 @@ def grads_digest(grads):
     return np.stack([digest(g) if g is not None else np.full(20, np.nan) for g in grads])
 
 
-def capture(name, seed, P, W, H, blocks, variance, depth, T, n_epi, mb):
+def capture(name, seed, P, W, H, blocks, variance, depth, T, n_epi, mb, E=128):
     from environment.pursuit_evasion_game.pursuit_env import Pursuit_Env
     from DHGN.mappo_parallel import MAPPO, AttributeDataset, EmbeddingDataset2
     from DHGN.replay_buffer import BigBuffer
@@ -47,6 +47,8 @@ def capture(name, seed, P, W, H, blocks, variance, depth, T, n_epi, mb):
     cfg = refload.load_cfg(num_defender=P, map_size=(W, H), blocks=blocks, variance=variance, depth=depth, max_steps=T)
     cfg.algo.sample_epi_num = n_epi
     cfg.algo.max_train_steps = 100000
+    cfg.algo.embedding_dim = E
+    cfg.algo.rnn_hidden_dim = E
     refload.seed_all(seed)
     env = Pursuit_Env(cfg)
     agent = MAPPO(cfg, n_epi, mb, "Learner")
@@ -55,6 +57,13 @@ def capture(name, seed, P, W, H, blocks, variance, depth, T, n_epi, mb):
     names_c, dig_c = sd_digest(agent.critic.state_dict())
     out["actor_keys"] = np.asarray(names_a); out["critic_keys"] = np.asarray(names_c)
     out["actor_init_digest"] = dig_a; out["critic_init_digest"] = dig_c
+    # the initial weights themselves: orthogonal_ goes through LAPACK, whose last bits differ between CPU models,
+    # so re-creating them from the seed is only reproducible on the machine that made the fixture
+    for k, v in agent.actor.state_dict().items():
+        out["w_actor_" + k] = v.numpy().copy()
+    for k, v in agent.critic.state_dict().items():
+        if not k.startswith("shared_net."):
+            out["w_critic_" + k] = v.numpy().copy()
     with torch.no_grad():  # make the policy input-sensitive so greedy actions are not degenerate at init
         for key, fac in SHARPEN_OPS:
             dict(agent.actor.named_parameters())[key].mul_(fac)
@@ -176,7 +185,7 @@ def capture(name, seed, P, W, H, blocks, variance, depth, T, n_epi, mb):
     for j, tgt in enumerate(drawn[n_before][1:][:16]):
         et[j] = tgt
     out["eval_tape"] = et
-    out["meta"] = np.asarray([seed, P, W, H, blocks, variance, depth, T, n_epi, mb], np.int64)
+    out["meta"] = np.asarray([seed, P, W, H, blocks, variance, depth, T, n_epi, mb, E], np.int64)
     out["sharpen_keys"] = np.asarray([k for k, _ in SHARPEN_OPS]); out["sharpen_factors"] = np.asarray([f for _, f in SHARPEN_OPS])
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "objC", objC, "objA", objA, "evalR", R, "logp range", float(logp.min()), float(logp.max()),
@@ -184,7 +193,7 @@ def capture(name, seed, P, W, H, blocks, variance, depth, T, n_epi, mb):
 
 
 def main():
-    capture("model_p4_20x20_d1", seed=11, P=4, W=20, H=20, blocks=2, variance=4, depth=1, T=16, n_epi=4, mb=2)
+    capture("model_p4_20x20_d1", seed=11, P=4, W=20, H=20, blocks=2, variance=4, depth=1, T=16, n_epi=4, mb=2, E=64)
     capture("model_p8_40x40_d3", seed=13, P=8, W=40, H=40, blocks=5, variance=10, depth=3, T=12, n_epi=3, mb=2)
 
 

@@ -1,0 +1,146 @@
+"""GPU parity of the product MAPPO (batched HIP env + fused ops + torch) against goldens captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import buffer_tensors, digest, golden_cfg, load_golden_weights, load_model_golden, sharpen
+
+pytestmark = pytest.mark.gpu
+NAMES = ["model_p4_20x20_d1", "model_p8_40x40_d3"]
+
+
+def close(a, b, tol):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, np.float64); b = np.asarray(b, np.float64)
+    return np.max(np.abs(a - b)) <= tol * (1.0 + np.max(np.abs(b)))
+
+
+def make_agent(d, agent_type="Learner", **extra):
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import MAPPO
+    cfg = golden_cfg(d, **extra)
+    torch.manual_seed(d["seed"])
+    agent = MAPPO(cfg, d["n_epi"], d["mb"], agent_type)
+    load_golden_weights(d, agent.actor, agent.critic)
+    return cfg, agent
+
+
+def episode_inits(d, prefix="init_", n=None):
+    inits = []
+    n = d["n_epi"] if n is None else n
+    for k in range(n):
+        inits.append(dict(grid=d[prefix + "grid"][k:k + 1], obs_xy=d[prefix + "obs_xy"][k:k + 1], n_obs=d[prefix + "n_obs"][k:k + 1],
+                          defenders=d[prefix + "defenders"][k:k + 1], evader=d[prefix + "evader"][k:k + 1],
+                          target=d[prefix + "target"][k:k + 1], tape=d[prefix + "tape"][k:k + 1]))
+    return inits
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_rollout_reproduces_reference_buffer(name):
+    """One environment, n_epi sequential episodes like one reference Worker; recorded initial conditions and the
+    reference's sampled actions are injected, everything else (env, observations, model, reward norm) is ours."""
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    d = load_model_golden(name)
+    cfg, agent = make_agent(d, "Worker")
+    for m, dg in ((agent.actor, d["actor_init_digest"]), (agent.critic, d["critic_init_digest"])):
+        for (k, v), ref in zip(m.state_dict().items(), dg):
+            assert np.array_equal(digest(v.float()), ref), k
+    assert agent.actor.shared_net.MSG_layers[0].weight.data_ptr() == agent.critic.shared_net.MSG_layers[0].weight.data_ptr()
+    sharpen(d, agent.actor)
+    env = Pursuit_Env(cfg, num_envs=1)
+    acts = torch.as_tensor(d["buf_a_n"]).long()
+    inits = episode_inits(d)
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import ReplayBuffer
+    agent.minibuffer = ReplayBuffer(cfg, d["n_epi"], agent.device).reset_buffer()
+    tot = 0.0
+    for k in range(d["n_epi"]):
+        r, steps = agent.run_episode(env, num_episode=k, actions_override=acts, init=inits[k])
+        tot += float(r.sum())
+        assert steps == d["T"]
+    buf = agent.minibuffer.buffer
+    assert abs(tot / d["n_epi"] - float(d["exp_reward"])) < 1e-6
+    for key in ("p_state", "e_state", "p_adj", "e_adj", "o_adj", "a_n", "active"):
+        assert np.array_equal(buf[key].cpu().numpy(), d["buf_" + key]), key          # exact: env + bookkeeping
+    assert np.array_equal(agent.minibuffer.o_static.cpu().numpy(), d["buf_o_state"][:, 0])
+    assert close(buf["r"], d["buf_r"], 1e-6)
+    for key in ("a_logprob_n", "v_n", "actor_historical_embedding", "critic_historical_embedding"):
+        assert close(buf[key], d["buf_" + key], 1e-4), key                          # fp32 model: 1e-4
+    n, mean, S = int(env.sim.rn[0, 0].item()), env.sim.rn[0, 1:1 + d["P"]].cpu().numpy(), env.sim.rn[0, 1 + d["P"]:].cpu().numpy()
+    assert n == int(d["rn_n"]) and np.array_equal(mean, d["rn_mean"]) and np.array_equal(S, d["rn_S"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_sequence_mode_and_train_reproduce_reference(name):
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import ReplayBuffer
+    d = load_model_golden(name)
+    cfg, agent = make_agent(d, "Learner")
+    sharpen(d, agent.actor)
+    rb = ReplayBuffer.from_tensors(cfg, buffer_tensors(d), d["init_n_obs"], agent.device)
+    b = rb.buffer
+    N, T, P = b["r"].shape
+    R = N * T
+    dep = d["depth"]
+    obs = dict(p_state=b["p_state"].reshape(R, P, -1), e_state=b["e_state"].reshape(R, 1, -1), o_state=rb.o_static, q_div=T,
+               p_adj=b["p_adj"].reshape(R, P, P), e_adj=b["e_adj"].reshape(R, P, 1), o_adj=b["o_adj"].reshape(R, P, -1))
+    ha = [b["actor_historical_embedding"][:, dep - 1 - k: dep - 1 - k + T].reshape(R, P, -1) for k in range(dep)]
+    hc = [b["critic_historical_embedding"][:, dep - 1 - k: dep - 1 - k + T].reshape(R, P, -1) for k in range(dep)]
+    with torch.no_grad():
+        logp, ent = agent.actor.get_logprob_and_entropy(obs, ha, b["a_n"], N, T)
+        vals = agent.critic(obs, hc, None, 1, N, T).squeeze(-1)
+    assert close(logp, d["m1_logp"], 1e-4) and close(ent, d["m1_entropy"], 1e-4) and close(vals, d["m1_values"], 1e-4)
+    # train(): GAE, losses, accumulated + clipped gradients
+    objC, objA, ag, cg = agent.train(rb, int(d["steps"]))
+    assert close(agent.last_adv, d["gae_adv"], 1e-4) and close(agent.last_v_target, d["gae_v_target"], 1e-4)
+    assert abs(objC - float(d["objC"])) <= 1e-4 * (1 + abs(float(d["objC"])))
+    assert abs(objA - float(d["objA"])) <= 1e-4 * (1 + abs(float(d["objA"])))
+    assert abs(agent.ac_optimizer.param_groups[0]["lr"] - float(d["lr_after_train"])) < 1e-12
+    for grads, dg, m in ((ag, d["actor_grad_digest"], agent.actor), (cg, d["critic_grad_digest"], agent.critic)):
+        names = [n for n, _ in m.named_parameters()]
+        assert len(grads) == len(dg)
+        for k, g, ref in zip(names, grads, dg):
+            mine = digest(g)
+            scale = max(1e-6, ref[2] / ref[0])
+            assert abs(mine[2] - ref[2]) <= 3e-3 * ref[2] + 1e-7, (k, mine[2], ref[2])
+            assert np.max(np.abs(mine[4:] - ref[4:])) <= 3e-3 * max(scale, np.max(np.abs(ref[4:]))) + 1e-7, k
+    pa = dict(agent.actor.named_parameters())
+    for key in ("shared_net.MSG_layers.2.weight", "shared_net.MSG_layers.0.weight", "Mean.weight", "shared_net.MSG_layers.2.bias"):
+        ref = d["agrad_" + key]
+        assert np.max(np.abs(pa[key].grad.cpu().numpy() - ref)) <= 2e-3 * np.max(np.abs(ref)) + 1e-7, key
+    # Learner.set_gradients_and_update (runner.py:72-78)
+    from distributed_multi_agent_reinforcement_learning_amd.runner import Learner
+    lrn = Learner.__new__(Learner)
+    lrn.agent, lrn.learner_device, lrn.use_lr_decay = agent, agent.device, True
+    lrn.set_gradients_and_update(ag, cg, int(d["steps"]))
+    for m, dg, keys in ((agent.actor, d["actor_upd_digest"], d["actor_keys"]), (agent.critic, d["critic_upd_digest"], d["critic_keys"])):
+        sd = m.state_dict()
+        for k, ref in zip(keys, dg):
+            k = str(k)
+            if k.endswith(("weight_u", "weight_v")):
+                continue
+            mine = digest(sd[k])
+            assert abs(mine[1] - ref[1]) <= 1e-4 * ref[2] + 1e-6, (k, mine[1], ref[1])
+            assert np.max(np.abs(mine[4:] - ref[4:])) <= 3e-4, k
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_greedy_evaluate_action_indices_bit_exact(name):
+    """north star: bit-exact action indices for greedy eval.  The golden evaluate ran on the post-update weights, so the
+    update is replayed first (its parity is covered above)."""
+    from distributed_multi_agent_reinforcement_learning_amd.evaluator import evaluate
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import ReplayBuffer
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from distributed_multi_agent_reinforcement_learning_amd.runner import Learner
+    d = load_model_golden(name)
+    cfg, agent = make_agent(d, "Learner")
+    sharpen(d, agent.actor)
+    rb = ReplayBuffer.from_tensors(cfg, buffer_tensors(d), d["init_n_obs"], agent.device)
+    _, _, ag, cg = agent.train(rb, int(d["steps"]))
+    lrn = Learner.__new__(Learner)
+    lrn.agent, lrn.learner_device, lrn.use_lr_decay = agent, agent.device, True
+    lrn.set_gradients_and_update(ag, cg, int(d["steps"]))
+    env = Pursuit_Env(cfg, num_envs=1)
+    init = dict(grid=d["eval_grid"][None], obs_xy=d["eval_obs_xy"][None], n_obs=np.asarray([d["eval_n_obs"]], np.int32),
+                defenders=d["eval_defenders"][None], evader=d["eval_evader"][None], target=d["eval_target"][None], tape=d["eval_tape"][None])
+    with torch.no_grad():
+        R, last, acts = evaluate(env, agent.actor, cfg, init=init, return_actions=True)
+    assert last == int(d["eval_last_index"])
+    assert np.array_equal(acts[0].cpu().numpy(), d["eval_actions"])
+    assert abs(float(R[0]) - float(d["eval_return"])) < 1e-6

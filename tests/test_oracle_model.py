@@ -22,12 +22,15 @@ def clone_sd(m):
 @pytest.mark.parametrize("name", NAMES)
 def test_module_construction_reproduces_reference_weights(name):
     d = load_model_golden(name)
-    cfg, actor, critic = golden_models(d)
+    cfg, actor, critic = golden_models(d, from_seed=True)
     assert list(actor.state_dict().keys()) == [str(k) for k in d["actor_keys"]]
     assert list(critic.state_dict().keys()) == [str(k) for k in d["critic_keys"]]
-    for m, dg in ((actor, d["actor_init_digest"]), (critic, d["critic_init_digest"])):
+    for m, dg, pre in ((actor, d["actor_init_digest"], "w_actor_"), (critic, d["critic_init_digest"], "w_critic_")):
         for (k, v), ref in zip(m.state_dict().items(), dg):
-            assert np.array_equal(digest(v.float()), ref), k
+            # same generator stream and initialisers as the reference; orthogonal_ (LAPACK QR) may differ in the last
+            # bits on another CPU model, everything else is exact
+            assert np.allclose(digest(v.float()), ref, rtol=1e-5, atol=1e-6), k
+            assert v.shape == tuple(d[("w_actor_" if k.startswith("shared_net.") else pre) + k].shape)
     assert [n for n, _ in actor.named_parameters()] == [str(k) for k in d["actor_keys"]]
     assert actor.shared_net is critic.shared_net
 
