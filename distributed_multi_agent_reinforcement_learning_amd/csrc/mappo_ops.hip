@@ -154,13 +154,18 @@ __global__ void k_msg_agg_bwd(MsgArgs a, const float *gout, float *partials) {
     dst[a.din * E + f] = gb;
 }
 
+// one workgroup per output element group: 64 lanes split the partial blocks, then a wave reduction (deterministic order)
 __global__ void k_msg_agg_bwd_reduce(int nblk, int E, int din, const float *partials, float *dW, float *db) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (din+1)*E
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // over (din+1)*E, one wave each
+    const int lane = threadIdx.x & 63;
     if (idx >= (din + 1) * E) return;
     double s = 0.0;
-    for (int b = 0; b < nblk; b++) s += (double)partials[(size_t)b * (din + 1) * E + idx];
-    const int k = idx / E, f = idx - k * E;
-    if (k < din) dW[(size_t)f * din + k] = (float)s; else db[f] = (float)s;
+    for (int b = lane; b < nblk; b += 64) s += (double)partials[(size_t)b * (din + 1) * E + idx];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        const int k = idx / E, f = idx - k * E;
+        if (k < din) dW[(size_t)f * din + k] = (float)s; else db[f] = (float)s;
+    }
 }
 
 // ---- GAE ---------------------------------------------------------------------------------------------------
@@ -251,6 +256,70 @@ __global__ void k_categorical(int R, int A, const float *probs, uint64_t seed, u
     }
 }
 
+
+// ---- GRU gate math (torch.nn.GRU cell; reference DHGN/mappo_parallel.py:397,424,434) ------------------------------
+// gi = x W_ih^T + b_ih and gh = h W_hh^T come from MFMA GEMMs (rocBLAS/hipBLASLt fp32); everything between them and
+// the next step's GEMM is fused here: bias, sigmoid/tanh, the state update and (for training) the saved gates.
+//   r = s(gi_r + gh_r + bhh_r); z = s(gi_z + gh_z + bhh_z); hn = gh_n + bhh_n; n = tanh(gi_n + r * hn); h' = (1-z) n + z h
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void k_gru_gates_fwd(int B, int H, const float *gi, const float *gh, const float *bhh, const float *hprev, float *hout,
+                                float *save /* [4][B][H]: r, z, n, hn or NULL */) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over B*H/4
+    const int H4 = H >> 2;
+    if (idx >= B * H4) return;
+    const int b = idx / H4, c = (idx - b * H4) << 2;
+    const float4 gir = *(const float4 *)(gi + (size_t)b * 3 * H + c), giz = *(const float4 *)(gi + (size_t)b * 3 * H + H + c),
+                 gin = *(const float4 *)(gi + (size_t)b * 3 * H + 2 * H + c);
+    const float4 ghr = *(const float4 *)(gh + (size_t)b * 3 * H + c), ghz = *(const float4 *)(gh + (size_t)b * 3 * H + H + c),
+                 ghn = *(const float4 *)(gh + (size_t)b * 3 * H + 2 * H + c);
+    const float4 br = *(const float4 *)(bhh + c), bz = *(const float4 *)(bhh + H + c), bn = *(const float4 *)(bhh + 2 * H + c);
+    const float4 hp = *(const float4 *)(hprev + (size_t)b * H + c);
+    float4 r, z, n, hn, ho;
+#define GRU_ONE(f)                                  \
+    r.f = sigmoidf_(gir.f + ghr.f + br.f);          \
+    z.f = sigmoidf_(giz.f + ghz.f + bz.f);          \
+    hn.f = ghn.f + bn.f;                            \
+    n.f = tanhf(gin.f + r.f * hn.f);                \
+    ho.f = (1.f - z.f) * n.f + z.f * hp.f;
+    GRU_ONE(x) GRU_ONE(y) GRU_ONE(z) GRU_ONE(w)
+#undef GRU_ONE
+    *(float4 *)(hout + (size_t)b * H + c) = ho;
+    if (save) {
+        const size_t BH = (size_t)B * H, o = (size_t)b * H + c;
+        *(float4 *)(save + o) = r; *(float4 *)(save + BH + o) = z; *(float4 *)(save + 2 * BH + o) = n; *(float4 *)(save + 3 * BH + o) = hn;
+    }
+}
+
+// dh = dout (may be NULL) + dh_carry ; outputs dgi [B][3H], dgh [B][3H], dh_direct [B][H] (= dh * z)
+__global__ void k_gru_gates_bwd(int B, int H, const float *dout, const float *dcarry, const float *save, const float *hprev, float *dgi,
+                                float *dgh, float *dhdirect) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int H4 = H >> 2;
+    if (idx >= B * H4) return;
+    const int b = idx / H4, c = (idx - b * H4) << 2;
+    const size_t BH = (size_t)B * H, o = (size_t)b * H + c;
+    const float4 r = *(const float4 *)(save + o), z = *(const float4 *)(save + BH + o), n = *(const float4 *)(save + 2 * BH + o),
+                 hn = *(const float4 *)(save + 3 * BH + o);
+    const float4 hp = *(const float4 *)(hprev + o);
+    float4 dh = dcarry ? *(const float4 *)(dcarry + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dout) { const float4 d2 = *(const float4 *)(dout + o); dh.x += d2.x; dh.y += d2.y; dh.z += d2.z; dh.w += d2.w; }
+    float4 dr, dz, dn, dnr, dd;
+#define GRU_ONE(f)                                           \
+    {                                                        \
+        const float dn_ = dh.f * (1.f - z.f) * (1.f - n.f * n.f); \
+        const float dz_ = dh.f * (hp.f - n.f) * z.f * (1.f - z.f); \
+        const float dr_ = dn_ * hn.f * r.f * (1.f - r.f);    \
+        dr.f = dr_; dz.f = dz_; dn.f = dn_; dnr.f = dn_ * r.f; dd.f = dh.f * z.f; \
+    }
+    GRU_ONE(x) GRU_ONE(y) GRU_ONE(z) GRU_ONE(w)
+#undef GRU_ONE
+    float *gi = dgi + (size_t)b * 3 * H + c, *gh = dgh + (size_t)b * 3 * H + c;
+    *(float4 *)(gi) = dr; *(float4 *)(gi + H) = dz; *(float4 *)(gi + 2 * H) = dn;
+    *(float4 *)(gh) = dr; *(float4 *)(gh + H) = dz; *(float4 *)(gh + 2 * H) = dnr;
+    *(float4 *)(dhdirect + o) = dd;
+}
+
 size_t msg_lds_bytes(int P, int K) { return sizeof(float) * (size_t)(K * 4 + ((P * K + 3) & ~3) + P * 4 + P * 4 + MAX_P + 4); }
 
 int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, const void *adj, const void *kvalid, const void *e) {
@@ -263,7 +332,7 @@ int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, cons
     return 0;
 }
 
-constexpr int BWD_BLOCKS = 2048;
+constexpr int BWD_BLOCKS = 1024;
 
 }  // namespace
 
@@ -296,7 +365,7 @@ int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
     const int grid = R < BWD_BLOCKS ? (R > 0 ? R : 1) : BWD_BLOCKS;
     hipLaunchKernelGGL(k_msg_agg_bwd, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);
     const int tot = (din + 1) * E;
-    hipLaunchKernelGGL(k_msg_agg_bwd_reduce, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, grid, E, din,
+    hipLaunchKernelGGL(k_msg_agg_bwd_reduce, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, grid, E, din,
                        (const float *)workspace, dW, db);
     return (int)hipGetLastError();
 }
@@ -325,6 +394,23 @@ int categorical_sample(int32_t R, int32_t A, const float *probs, uint64_t seed, 
     if (R < 0 || A < 1 || !probs || !action) return MO_ERR_BAD_ARG;
     if (R == 0) return 0;
     hipLaunchKernelGGL(k_categorical, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, A, probs, seed, offset, greedy, action, logp);
+    return (int)hipGetLastError();
+}
+
+int gru_gates_fwd(int32_t B, int32_t H, const float *gi, const float *gh, const float *b_hh, const float *h_prev, float *h_out,
+                  float *save, void *stream) {
+    if (B < 1 || H < 4 || (H & 3) || !gi || !gh || !b_hh || !h_prev || !h_out) return MO_ERR_BAD_ARG;
+    const int n = B * (H >> 2);
+    hipLaunchKernelGGL(k_gru_gates_fwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, H, gi, gh, b_hh, h_prev, h_out, save);
+    return (int)hipGetLastError();
+}
+
+int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, const float *save, const float *h_prev, float *dgi,
+                  float *dgh, float *dh_direct, void *stream) {
+    if (B < 1 || H < 4 || (H & 3) || !save || !h_prev || !dgi || !dgh || !dh_direct) return MO_ERR_BAD_ARG;
+    const int n = B * (H >> 2);
+    hipLaunchKernelGGL(k_gru_gates_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, H, dout, dcarry, save, h_prev, dgi, dgh,
+                       dh_direct);
     return (int)hipGetLastError();
 }
 

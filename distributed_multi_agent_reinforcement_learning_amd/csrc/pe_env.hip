@@ -36,12 +36,14 @@ struct Lds {
     double *eva;     // [4]
     float *oadj;     // [P*O]
     uint8_t *cond;   // [P*P]
-    int32_t *misc;   // [16]
+    int32_t *misc;   // [8 + 2*PE_MAX_P]: t, path_len, path_cnt, ..., rounded defender cells
     // replan scratch
     uint8_t *obs;    // [(W+1)*(H+1)]
-    uint8_t *open;   // [(W+1)*(H+1)]
+    uint8_t *open;   // [(W+1)*(H+1)]  node is in the OPEN list
     uint16_t *parent;  // [(W+1)*(H+1)]
+    uint16_t *olist; // [(W+1)*(H+1)]  compact OPEN list (unordered)
     double *g;       // [(W+1)*(H+1)]
+    unsigned long long *red;  // [2]  wave arg-min scratch
 };
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -51,13 +53,15 @@ __host__ __device__ inline size_t lds_layout(const pe_config &c, bool with_obs, 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
     size_t o_g = take(sizeof(double) * (with_replan ? NN : 0));
+    size_t o_red = take(sizeof(unsigned long long) * 2);
     size_t o_def = take(sizeof(double) * 4 * P);
     size_t o_prop = take(sizeof(double) * 4 * P);
     size_t o_eva = take(sizeof(double) * 4);
     size_t o_oadj = take(sizeof(float) * (with_obs ? P * c.O : 0));
-    size_t o_misc = take(sizeof(int32_t) * 16);
+    size_t o_misc = take(sizeof(int32_t) * (8 + 2 * PE_MAX_P));
     size_t o_bidx = take(sizeof(int16_t) * (with_obs ? WH : 0));
     size_t o_parent = take(sizeof(uint16_t) * (with_replan ? NN : 0));
+    size_t o_olist = take(sizeof(uint16_t) * (with_replan ? NN : 0));
     size_t o_grid = take(WH);
     size_t o_cond = take(P * P);
     size_t o_obs = take(with_replan ? NN : 0);
@@ -71,6 +75,8 @@ __host__ __device__ inline size_t lds_layout(const pe_config &c, bool with_obs, 
         l->misc = (int32_t *)(base + o_misc);
         l->bidx = (int16_t *)(base + o_bidx);
         l->parent = (uint16_t *)(base + o_parent);
+        l->olist = (uint16_t *)(base + o_olist);
+        l->red = (unsigned long long *)(base + o_red);
         l->grid = base + o_grid;
         l->cond = base + o_cond;
         l->obs = base + o_obs;
@@ -274,10 +280,12 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
 }
 
 // ---- weighted A* (astar.py:26-161) on an LDS-resident problem ------------------------------------------
-// OPEN is a per-node flag; the pop is a wave-wide arg-min of (f, x, y) over open nodes, which is the order
-// heapq yields for (f, (x, y)) tuples.  Stale duplicates of the reference's heap never change g/PARENT when
-// popped (same g, same sums), so keeping only the live entry per node is equivalent.
-// Returns the true path length (goal -> start); stores the last min(len, max_path) nodes in path_out (HBM).
+// OPEN is a compact unordered list of node ids in LDS (at most one live entry per node); the pop is a wave-wide
+// arg-min of (f, x, y) over the list, which is the order heapq yields for (f, (x, y)) tuples: lanes scan the list,
+// one ds_min_u64 on the bit pattern of f (f >= 0, so the pattern is monotone) finds the minimum, a ds_min_u32 over
+// the lanes that hold it breaks ties by node id (id order == (x, y) tuple order).  Stale duplicates of the
+// reference's heap never change g/PARENT when popped (same g, same sums), so keeping only the live entry is
+// equivalent.  Returns the true path length (goal -> start); stores the last min(len, max_path) nodes in path_out.
 __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, int gx, int gy, int16_t *path_out, int max_path,
                          int *n_stored, int *n_expanded, int *status) {
     const int SY = H + 1, NN = (W + 1) * SY;
@@ -294,47 +302,66 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         l.parent[s_id] = (uint16_t)s_id;
         l.g[s_id] = (s_id == g_id) ? __builtin_inf() : 0.0;  // astar.py:39-40: g[goal] = inf overrides g[start]
         l.open[s_id] = 1;
+        l.olist[0] = (uint16_t)s_id;
     }
+    int cnt = 1;  // wave-uniform length of the OPEN list
+    unsigned int *red32 = (unsigned int *)(l.red + 1);
     wave_sync();
     const int cap = 16 * NN;  // every wave leaves the loop: the open set drains or the cap trips
     int expanded = 0;
-    for (int it = 0; it < cap; it++) {
-        // --- pop: arg-min over open nodes of (f = g + 2.5 * manhattan, id) ; id order == (x, y) tuple order
-        double bf = __builtin_inf();
-        int bid = -1;
-        for (int i = lane; i < NN; i += WAVE) {
-            if (l.open[i]) {
-                int x = i / SY, y = i - x * SY;
-                double f = l.g[i] + 2.5 * (double)(abs(gx - x) + abs(gy - y));
-                if (bid < 0 || f < bf || (f == bf && i < bid)) { bf = f; bid = i; }
-            }
+    for (int it = 0; it < cap && cnt > 0; it++) {
+        // --- pop: arg-min over OPEN of (f = g + 2.5 * manhattan, id)
+        unsigned long long bk = ~0ull;
+        unsigned int bsel = ~0u;
+        for (int sl = lane; sl < cnt; sl += WAVE) {
+            const int id = l.olist[sl];
+            const int x = id / SY, y = id - x * SY;
+            const double f = l.g[id] + 2.5 * (double)(abs(gx - x) + abs(gy - y));
+            const unsigned long long k = (unsigned long long)__double_as_longlong(f);
+            const unsigned int sel = ((unsigned int)id << 16) | (unsigned int)sl;
+            if (k < bk || (k == bk && sel < bsel)) { bk = k; bsel = sel; }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            double of = __shfl_xor(bf, off);
-            int oid = __shfl_xor(bid, off);
-            if (oid >= 0 && (bid < 0 || of < bf || (of == bf && oid < bid))) { bf = of; bid = oid; }
-        }
-        if (bid < 0) break;  // OPEN empty
+        if (lane == 0) { l.red[0] = ~0ull; red32[0] = ~0u; }
+        wave_sync();
+        if (bsel != ~0u) atomicMin(&l.red[0], bk);
+        wave_sync();
+        if (bsel != ~0u && bk == l.red[0]) atomicMin(&red32[0], bsel);
+        wave_sync();
+        const unsigned int sel = red32[0];
+        const int bid = (int)(sel >> 16), slot = (int)(sel & 0xFFFFu);
         expanded++;
         if (bid == g_id) break;
         const int cx = bid / SY, cy = bid - cx * SY;
         const double gc = l.g[bid];
         const bool cur_blocked = l.obs[bid] != 0;  // is_collision(s_start=cur, .) (astar.py:106-107)
+        const int last = l.olist[cnt - 1];
         wave_sync();
-        if (lane == 0) l.open[bid] = 0;
+        if (lane == 0) { l.open[bid] = 0; l.olist[slot] = (uint16_t)last; }
+        cnt -= 1;
+        wave_sync();
+        bool push = false;
+        int nid = 0;
         if (lane < 8 && !cur_blocked) {
             // u_set order (-1,0),(-1,1),(0,1),(1,1),(1,0),(1,-1),(0,-1),(-1,-1) (astar.py:11-12); neighbours are distinct
             const int ux = (lane < 2 || lane == 7) ? -1 : ((lane >= 3 && lane <= 5) ? 1 : 0);
             const int uy = (lane >= 1 && lane <= 3) ? 1 : ((lane >= 5) ? -1 : 0);
-            int nx = cx + ux, ny = cy + uy;
+            const int nx = cx + ux, ny = cy + uy;
             if (nx >= 0 && nx <= W && ny >= 0 && ny <= H) {  // '>' bounds: x == W and y == H are legal (astar.py:109-113)
-                int nid = nx * SY + ny;
+                nid = nx * SY + ny;
                 if (!l.obs[nid]) {
-                    double nc = gc + ((ux != 0 && uy != 0) ? SQRT2 : 1.0);
-                    if (nc < l.g[nid]) { l.g[nid] = nc; l.parent[nid] = (uint16_t)bid; l.open[nid] = 1; }
+                    const double nc = gc + ((ux != 0 && uy != 0) ? SQRT2 : 1.0);
+                    if (nc < l.g[nid]) {
+                        l.g[nid] = nc;
+                        l.parent[nid] = (uint16_t)bid;
+                        push = l.open[nid] == 0;
+                        l.open[nid] = 1;
+                    }
                 }
             }
         }
+        const unsigned long long pm = __ballot(push);
+        if (push) l.olist[cnt + __popcll(pm & ((1ull << lane) - 1ull))] = (uint16_t)nid;
+        cnt += __popcll(pm);
         wave_sync();
         if (it == cap - 1) *status |= PE_STATUS_ASTAR_CAP;
     }
@@ -350,10 +377,10 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         int s = g_id;
         for (int k = 0; k < NN + 1; k++) { s = l.parent[s]; len++; if (s == s_id) break; }
     }
-    const int cnt = len < max_path ? len : max_path;
+    const int cnt_out = len < max_path ? len : max_path;
     if (lane == 0) {
         int s = g_id, k = 0;
-        const int skip = len - cnt;
+        const int skip = len - cnt_out;
         for (;;) {
             if (k >= skip) { path_out[2 * (k - skip)] = (int16_t)(s / SY); path_out[2 * (k - skip) + 1] = (int16_t)(s % SY); }
             k++;
@@ -361,7 +388,7 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
             s = l.parent[s];
         }
     }
-    *n_stored = cnt;
+    *n_stored = cnt_out;
     return len;
 }
 
@@ -372,6 +399,8 @@ __device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int32_t *
     const int gx = target[0], gy = target[1];
     int ext = c.extend_dis;
     int len = 1, cnt = 1, total_exp = 0, status = 0;
+    if (lane < P) { l.misc[8 + 2 * lane] = py_round(l.def[lane]); l.misc[8 + 2 * lane + 1] = py_round(l.def[P + lane]); }
+    wave_sync();
     while (ext >= 0) {
         // OBS = static U inflate(static, ext) U {visible cells that only the defender-augmented map blocks}
         const int vr = c.evader_view;
@@ -390,10 +419,8 @@ __device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int32_t *
                                    (norm2((double)dx, (double)dy) <= (double)vr);
                     if (visible) {
                         bool pred = false;
-                        for (int k = 0; k < P; k++) {
-                            int px = py_round(l.def[k]), py = py_round(l.def[P + k]);
-                            if (abs(px - x) <= ext && abs(py - y) <= ext) pred = true;
-                        }
+                        for (int k = 0; k < P; k++)
+                            if (abs(l.misc[8 + 2 * k] - x) <= ext && abs(l.misc[8 + 2 * k + 1] - y) <= ext) pred = true;
                         v = pred;
                     }
                 }

@@ -99,14 +99,14 @@ class _Trunk(nn.Module):
 
     def _rollout_features(self, embedding, hidden_state):
         R, P, E = embedding.shape
-        feat, hidden_state = self.GRU(embedding.reshape(1, R * P, E), hidden_state)
+        feat, hidden_state = ops.gru(embedding.reshape(1, R * P, E), hidden_state, self.GRU)
         return feat.reshape(R, P, self.rnn_hidden_dim), hidden_state
 
     def _sequence_features(self, embedding, batch, steps):
         P = embedding.shape[1]
         x = embedding.reshape(batch, steps, P, self.rnn_input_dim).permute(1, 0, 2, 3).reshape(steps, batch * P, self.rnn_input_dim)
         h0 = torch.zeros(self.num_layers, batch * P, self.rnn_hidden_dim, dtype=x.dtype, device=x.device)
-        feat, _ = self.GRU(x.contiguous(), h0)
+        feat, _ = ops.gru(x.contiguous(), h0, self.GRU)
         return feat.reshape(steps, batch, P, self.rnn_hidden_dim).permute(1, 0, 2, 3)
 
     def get_weights(self):

@@ -12,6 +12,7 @@ from . import build as _build
 
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
+           "gru_gates_fwd", "gru_gates_bwd",
            "mappo_ops_error_string")
 
 _lib = None
@@ -36,6 +37,8 @@ def load_library():
         L.dhgn_msg_agg_bwd_workspace.restype = i64
         L.gae_advnorm.argtypes = [i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
         L.categorical_sample.argtypes = [i32, i32, vp, C.c_uint64, C.c_uint64, i32, vp, vp, vp]
+        L.gru_gates_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.gru_gates_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mappo_ops_error_string.argtypes = [C.c_int]
         L.mappo_ops_error_string.restype = C.c_char_p
         _lib = L
@@ -159,3 +162,72 @@ def categorical_sample(probs, seed, offset, greedy=False):
     _check(L.categorical_sample(R, A, _ptr(pr), int(seed), int(offset), 1 if greedy else 0, _ptr(action), _ptr(logp), _stream()),
            "categorical_sample")
     return action.reshape(shape), logp.reshape(shape)
+
+
+class _GRULayer(torch.autograd.Function):
+    """One torch.nn.GRU layer over a sequence: the input projection and the recurrent projection are fp32 MFMA GEMMs
+    (rocBLAS / hipBLASLt), the gate math between them is the fused HIP kernel pair gru_gates_{fwd,bwd}."""
+
+    @staticmethod
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh):
+        L = load_library()
+        _need_gpu(x, "gru")
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        x = x.contiguous()
+        h0 = h0.contiguous()
+        gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t()).reshape(T, B, 3 * H)
+        out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
+        need = any(ctx.needs_input_grad)
+        save = torch.empty((T, 4, B, H), dtype=x.dtype, device=x.device) if need else None
+        gh = torch.empty((B, 3 * H), dtype=x.dtype, device=x.device)
+        w_hh_t = w_hh.t()
+        b_hh = b_hh.contiguous()
+        hprev = h0
+        st = _stream()
+        for t in range(T):
+            torch.mm(hprev, w_hh_t, out=gh)
+            _check(L.gru_gates_fwd(B, H, _ptr(gi[t]), _ptr(gh), _ptr(b_hh), _ptr(hprev), _ptr(out[t]),
+                                   _ptr(save[t]) if need else None, st), "gru_gates_fwd")
+            hprev = out[t]
+        if need:
+            ctx.save_for_backward(x, h0, w_ih, w_hh, out, save)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = load_library()
+        x, h0, w_ih, w_hh, out, save = ctx.saved_tensors
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        dout = dout.contiguous()
+        dgi = torch.empty((T, B, 3 * H), dtype=x.dtype, device=x.device)
+        dgh = torch.empty((T, B, 3 * H), dtype=x.dtype, device=x.device)
+        dh_direct = torch.empty((B, H), dtype=x.dtype, device=x.device)
+        dcarry = None
+        st = _stream()
+        for t in range(T - 1, -1, -1):
+            hprev = out[t - 1] if t > 0 else h0
+            _check(L.gru_gates_bwd(B, H, _ptr(dout[t]), _ptr(dcarry), _ptr(save[t]), _ptr(hprev), _ptr(dgi[t]), _ptr(dgh[t]),
+                                   _ptr(dh_direct), st), "gru_gates_bwd")
+            dcarry = torch.addmm(dh_direct, dgh[t], w_hh)
+        dgi2, dgh2 = dgi.reshape(T * B, 3 * H), dgh.reshape(T * B, 3 * H)
+        dw_hh = torch.mm(dgh[0].t(), h0)
+        if T > 1:
+            dw_hh.addmm_(dgh[1:].reshape((T - 1) * B, 3 * H).t(), out[:-1].reshape((T - 1) * B, H))
+        dw_ih = torch.mm(dgi2.t(), x.reshape(T * B, I))
+        dx = torch.mm(dgi2, w_ih).reshape(T, B, I) if ctx.needs_input_grad[0] else None
+        return dx, dcarry, dw_ih, dw_hh, dgi2.sum(0), dgh2.sum(0)
+
+
+def gru(x, h0, gru_module):
+    """torch.nn.GRU(x, h0) semantics (seq-first, unidirectional, no dropout) on the fused path.
+    x (T, B, I), h0 (num_layers, B, H) -> out (T, B, H), h_n (num_layers, B, H)."""
+    hn = []
+    inp = x
+    for layer in range(gru_module.num_layers):
+        w_ih, w_hh = getattr(gru_module, f"weight_ih_l{layer}"), getattr(gru_module, f"weight_hh_l{layer}")
+        b_ih, b_hh = getattr(gru_module, f"bias_ih_l{layer}"), getattr(gru_module, f"bias_hh_l{layer}")
+        inp = _GRULayer.apply(inp, h0[layer], w_ih, w_hh, b_ih, b_hh)
+        hn.append(inp[-1])
+    return inp, torch.stack(hn, 0)

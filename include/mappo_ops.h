@@ -68,6 +68,18 @@ int gae_advnorm(int32_t N, int32_t T, int32_t P, const float *r, const float *v,
 int categorical_sample(int32_t R, int32_t A, const float *probs, uint64_t seed, uint64_t offset, int32_t greedy,
                        int32_t *action, float *logp, void *stream);
 
+/*
+ * torch.nn.GRU cell between the two MFMA GEMMs (reference DHGN/mappo_parallel.py:397,424,434; gate order r, z, n):
+ *   r = s(gi_r + gh_r + b_hr) ; z = s(gi_z + gh_z + b_hz) ; hn = gh_n + b_hn ; n = tanh(gi_n + r hn) ; h' = (1-z) n + z h
+ * gi = x W_ih^T + b_ih [B][3H], gh = h W_hh^T [B][3H] (bias b_hh [3H] added here), h_prev / h_out [B][H];
+ * save (training) [4][B][H] receives r, z, n, hn.  The backward kernel turns dL/dh' (dout + dcarry, either may be
+ * NULL... dcarry may be NULL) into dgi, dgh [B][3H] and the direct path dh_direct = dh' * z [B][H].
+ */
+int gru_gates_fwd(int32_t B, int32_t H, const float *gi, const float *gh, const float *b_hh, const float *h_prev, float *h_out,
+                  float *save, void *stream);
+int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, const float *save, const float *h_prev, float *dgi,
+                  float *dgh, float *dh_direct, void *stream);
+
 const char *mappo_ops_error_string(int code);
 
 #ifdef __cplusplus
