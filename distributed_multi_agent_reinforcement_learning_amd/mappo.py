@@ -196,17 +196,6 @@ class MAPPO:
             p["lr"] = lr_now
         self.total_step = total_steps
 
-    # ---- gradient transport on the device (replaces the numpy lists of main.py:105-129) ---------------------
-    def flat_grads(self):
-        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.ac_parameters])
-
-    def set_flat_grads(self, flat):
-        o = 0
-        for p in self.ac_parameters:
-            n = p.numel()
-            p.grad = flat[o:o + n].view_as(p).clone()
-            o += n
-
     # ---- rollout (:731-827) -----------------------------------------------------------------------------------
     def explore_env(self, env, num_episode, actions_override=None, init=None):
         N = env.num_envs

@@ -43,6 +43,19 @@ def allreduce_sum_(flat):
     return flat
 
 
+def flat_grads(params):
+    """one contiguous fp32 bucket in ac_parameters order (missing gradients count as zeros)"""
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+
+
+def set_flat_grads(params, flat):
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[o:o + n].view_as(p).clone()
+        o += n
+
+
 def broadcast_weights_(modules, src=0):
     """initial weight sync from learner 0 (main.py:73-75)"""
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -97,8 +110,8 @@ class Trainer:
         for _ in range(int(cfg.algo.epochs)):
             with torch.enable_grad():
                 obj_c, obj_a, _, _ = agent.train(buffer, self.total_steps, return_grads=False)
-            flat = allreduce_sum_(agent.flat_grads())
-            agent.set_flat_grads(flat)
+            flat = allreduce_sum_(flat_grads(agent.ac_parameters))
+            set_flat_grads(agent.ac_parameters, flat)
             agent.ac_optimizer.step()
             if cfg.algo.use_lr_decay:
                 agent.lr_decay(self.total_steps)
