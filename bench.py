@@ -159,6 +159,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    rollout_ms, update_ms = tr.last_breakdown_ms()
     # roofline of the environment tick kernel: algorithmic bytes / measured launch duration
     t_tick = measure_env_tick(tr, args.tick_samples)
     bytes_per_step = algorithmic_bytes_per_env_step(P, W, H, O)
@@ -178,6 +179,7 @@ def main():
                                    f"DHGN depth {cfg.algo.depth} + 2-layer GRU actor/critic, rollout + PPO update",
                        "envs_per_gpu": N, "episode_steps": T, "mini_batch_size": tr.mini_batch_size, "parallelism": f"dp{world}"},
             "ppo_updates_per_s": round(args.steps * cfg.algo.epochs / dt, 4),
+            "breakdown_ms": {"rollout_incl_host_reset": round(rollout_ms, 1), "gae_ppo_update_allreduce_adam": round(update_ms, 1)},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -28,6 +28,30 @@ __device__ __forceinline__ double norm2(double a, double b) { return __builtin_s
 
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }  // one wave per workgroup: LDS visibility fence
 
+template <int CTRL>
+__device__ __forceinline__ unsigned int dpp_mov(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+// Wave-wide lexicographic arg-min of (kh, kl, ks); every lane ends up with the minimum triple.  Four row-rotate DPP
+// steps reduce inside the 16-lane rows on the VALU, two ds_bpermute steps combine the four rows.  (An LDS atomic-min on
+// one address would be serialised lane by lane by the compiler's atomic optimiser: ~14 scalar instructions per active lane.)
+__device__ __forceinline__ void wave_argmin3(unsigned int &kh, unsigned int &kl, unsigned int &ks) {
+#define PE_TAKE(oh, ol, os)                                                                   \
+    {                                                                                         \
+        const bool t = (oh) < kh || ((oh) == kh && ((ol) < kl || ((ol) == kl && (os) < ks))); \
+        kh = t ? (oh) : kh; kl = t ? (ol) : kl; ks = t ? (os) : ks;                           \
+    }
+#define PE_DPP_STEP(CTRL) { const unsigned int oh = dpp_mov<CTRL>(kh), ol = dpp_mov<CTRL>(kl), os = dpp_mov<CTRL>(ks); PE_TAKE(oh, ol, os) }
+    PE_DPP_STEP(0x121)  // row_ror:1
+    PE_DPP_STEP(0x122)  // row_ror:2
+    PE_DPP_STEP(0x124)  // row_ror:4
+    PE_DPP_STEP(0x128)  // row_ror:8
+    { const unsigned int oh = __shfl_xor(kh, 16), ol = __shfl_xor(kl, 16), os = __shfl_xor(ks, 16); PE_TAKE(oh, ol, os) }
+    { const unsigned int oh = __shfl_xor(kh, 32), ol = __shfl_xor(kl, 32), os = __shfl_xor(ks, 32); PE_TAKE(oh, ol, os) }
+#undef PE_DPP_STEP
+#undef PE_TAKE
+}
+
 struct Lds {
     uint8_t *grid;   // [W*H]
     int16_t *bidx;   // [W*H]
@@ -223,7 +247,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
         int i = idx / P, j = idx - i * P;
         l.cond[idx] = (i <= j) && (norm2(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= c.def_comm_range);
     }
-    for (int idx = lane; idx < P * O; idx += WAVE) l.oadj[idx] = 0.f;
+    if (!(c.pad0 & 4)) for (int idx = lane; idx < P * O; idx += WAVE) l.oadj[idx] = 0.f;
     wave_sync();
     if (o.p_adj) {
         for (int idx = lane; idx < P * P; idx += WAVE) {
@@ -257,7 +281,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
     }
     // LiDAR from the truncated cell of every defender (pursuit_env.py:29-53, :201): beams x ranges out of LDS
     if (o.o_adj) {
-        const int tasks = P * c.num_beams;
+        const int tasks = (c.pad0 & 1) ? 0 : P * c.num_beams;
         for (int task = lane; task < tasks; task += WAVE) {
             int i = task / c.num_beams, b = task - i * c.num_beams;
             int cx = (int)l.def[i], cy = (int)l.def[P + i];
@@ -274,7 +298,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
             }
         }
         wave_sync();
-        copy_out_f32(o.o_adj + (int64_t)env * o.o_adj_stride, l.oadj, P * O, lane);
+        if (!(c.pad0 & 2)) copy_out_f32(o.o_adj + (int64_t)env * o.o_adj_stride, l.oadj, P * O, lane);
     }
     wave_sync();
 }
@@ -296,6 +320,34 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         *n_stored = 1;
         return 1;
     }
+    // Reachability pre-check (maps up to 63x63): an 8-connected flood fill from the start on row bitmasks (lane = row y,
+    // bit = column x).  The search only tests edge endpoints (astar.py:98-118), so 8-connectivity is exact.  When the goal
+    // cannot be reached the reference's search drains its whole OPEN set and returns [s_start] (astar.py:67-71); that
+    // answer does not depend on the pop order, so the exhaustive exploration (the straggler of a launch) is skipped.
+    if (W + 1 <= 64 && H + 1 <= 64 && s_id != g_id) {
+        unsigned long long freem = 0ull;
+        if (lane <= H)
+            for (int x = 0; x <= W; x++) freem |= (unsigned long long)(l.obs[x * SY + lane] == 0) << x;
+        unsigned long long reach = (lane == sy) ? ((1ull << sx) & freem) : 0ull;
+        bool found = false;
+        for (int it = 0; it < NN; it++) {
+            unsigned long long up = __shfl_up(reach, 1), dn = __shfl_down(reach, 1);
+            if (lane == 0) up = 0ull;
+            if (lane == WAVE - 1) dn = 0ull;
+            unsigned long long m = reach | up | dn;
+            m |= (m << 1) | (m >> 1);
+            const unsigned long long nr = (reach | m) & freem;
+            const bool changed = nr != reach;
+            reach = nr;
+            if (__ballot(lane == gy && ((reach >> gx) & 1ull)) != 0ull) { found = true; break; }
+            if (__ballot(changed) == 0ull) break;
+        }
+        if (!found) {
+            if (lane == 0) { path_out[0] = (int16_t)sx; path_out[1] = (int16_t)sy; }
+            *n_stored = 1;
+            return 1;
+        }
+    }
     for (int i = lane; i < NN; i += WAVE) { l.g[i] = __builtin_inf(); l.open[i] = 0; l.parent[i] = 0xFFFF; }
     wave_sync();
     if (lane == 0) {
@@ -305,29 +357,22 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         l.olist[0] = (uint16_t)s_id;
     }
     int cnt = 1;  // wave-uniform length of the OPEN list
-    unsigned int *red32 = (unsigned int *)(l.red + 1);
     wave_sync();
     const int cap = 16 * NN;  // every wave leaves the loop: the open set drains or the cap trips
     int expanded = 0;
     for (int it = 0; it < cap && cnt > 0; it++) {
-        // --- pop: arg-min over OPEN of (f = g + 2.5 * manhattan, id)
-        unsigned long long bk = ~0ull;
-        unsigned int bsel = ~0u;
+        // --- pop: arg-min over OPEN of (f = g + 2.5 * manhattan, id); f >= 0, so its bit pattern orders like f
+        unsigned int kh = ~0u, kl = ~0u, ks = ~0u;
         for (int sl = lane; sl < cnt; sl += WAVE) {
             const int id = l.olist[sl];
             const int x = id / SY, y = id - x * SY;
             const double f = l.g[id] + 2.5 * (double)(abs(gx - x) + abs(gy - y));
             const unsigned long long k = (unsigned long long)__double_as_longlong(f);
-            const unsigned int sel = ((unsigned int)id << 16) | (unsigned int)sl;
-            if (k < bk || (k == bk && sel < bsel)) { bk = k; bsel = sel; }
+            const unsigned int h = (unsigned int)(k >> 32), lo = (unsigned int)k, sel = ((unsigned int)id << 16) | (unsigned int)sl;
+            if (h < kh || (h == kh && (lo < kl || (lo == kl && sel < ks)))) { kh = h; kl = lo; ks = sel; }
         }
-        if (lane == 0) { l.red[0] = ~0ull; red32[0] = ~0u; }
-        wave_sync();
-        if (bsel != ~0u) atomicMin(&l.red[0], bk);
-        wave_sync();
-        if (bsel != ~0u && bk == l.red[0]) atomicMin(&red32[0], bsel);
-        wave_sync();
-        const unsigned int sel = red32[0];
+        wave_argmin3(kh, kl, ks);
+        const unsigned int sel = ks;
         const int bid = (int)(sel >> 16), slot = (int)(sel & 0xFFFFu);
         expanded++;
         if (bid == g_id) break;
@@ -399,6 +444,7 @@ __device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int32_t *
     const int gx = target[0], gy = target[1];
     int ext = c.extend_dis;
     int len = 1, cnt = 1, total_exp = 0, status = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     if (lane < P) { l.misc[8 + 2 * lane] = py_round(l.def[lane]); l.misc[8 + 2 * lane + 1] = py_round(l.def[P + lane]); }
     wave_sync();
     while (ext >= 0) {
@@ -415,8 +461,8 @@ __device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int32_t *
                 v = dyn;
                 if (!dyn) {
                     int dx = sx - x, dy = sy - y;
-                    bool visible = (x >= sx - vr) && (x < sx + vr) && (y >= sy - vr) && (y < sy + vr) &&
-                                   (norm2((double)dx, (double)dy) <= (double)vr);
+                    // np.linalg.norm of an integer pair <= view range  <=>  dx^2 + dy^2 <= vr^2 (exact in integers)
+                    bool visible = (x >= sx - vr) && (x < sx + vr) && (y >= sy - vr) && (y < sy + vr) && (dx * dx + dy * dy <= vr * vr);
                     if (visible) {
                         bool pred = false;
                         for (int k = 0; k < P; k++)
@@ -440,6 +486,7 @@ __device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int32_t *
         meta[PE_META_PATH_CNT] = cnt;
         meta[PE_META_ASTAR_EXP] = total_exp;
         if (status) meta[PE_META_STATUS] |= status;
+        meta[PE_META_PAD] = (int32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);  // diagnostic: shader cycles / 16 of this replan
         l.misc[1] = len;
         l.misc[2] = cnt;
     }
@@ -516,8 +563,8 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
     Lds l;
     lds_layout(c, OBS, EVA && REPLAN, smem, &l);
     const int WH = c.W * c.H, P = c.P;
-    copy_in(l.grid, st.grid + (size_t)env * WH, WH, lane);
-    if (OBS) copy_in(l.bidx, st.bidx + (size_t)env * WH, WH * 2, lane);
+    if (!(c.pad0 & 8)) copy_in(l.grid, st.grid + (size_t)env * WH, WH, lane);
+    if (OBS && !(c.pad0 & 8)) copy_in(l.bidx, st.bidx + (size_t)env * WH, WH * 2, lane);
     double *def_hbm = st.def + (size_t)env * 4 * P;
     double *eva_hbm = st.eva + (size_t)env * 4;
     if (lane < 4 * P) l.def[lane] = def_hbm[lane];

@@ -105,7 +105,10 @@ class Trainer:
     def iterate(self):
         """rollout + `epochs` updates; returns (env_steps_this_iteration_all_ranks, exp_reward)."""
         cfg, agent = self.cfg, self.agent
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         exp_r, buffer, steps = agent.explore_env(self.env, int(cfg.algo.sample_epi_num))
+        ev[1].record()
         self.total_steps += steps * self.world
         for _ in range(int(cfg.algo.epochs)):
             with torch.enable_grad():
@@ -116,8 +119,14 @@ class Trainer:
             if cfg.algo.use_lr_decay:
                 agent.lr_decay(self.total_steps)
             self.last_log = (obj_c, obj_a)
+        ev[2].record()
         self.iteration += 1
+        self.last_events = ev  # (rollout incl. host reset, update) timings: read after a synchronize
         return steps * self.world, exp_r
+
+    def last_breakdown_ms(self):
+        ev = self.last_events
+        return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
 
 
 def train_agent_multiprocessing(cfg, max_iterations=None, num_eval_envs=16, eval_every=1):

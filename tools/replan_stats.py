@@ -1,0 +1,21 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from distributed_multi_agent_reinforcement_learning_amd.config import baseline_config
+from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+cfg = baseline_config("cfg2")
+env = Pursuit_Env(cfg, num_envs=4096)
+env.reset()
+for trial in range(3):
+    env.sim.t_host = 0
+    env.sim.meta[:, 0] = 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); env.sim.evader_step(); e1.record(); torch.cuda.synchronize()
+    ex = env.sim.meta[:, 5].float()
+    pl = env.sim.meta[:, 1].float()
+    q = torch.quantile(ex, torch.tensor([0.5, 0.9, 0.99, 1.0], device="cuda"))
+    cyc = env.sim.meta[:, 7].float() * 16
+    qc = torch.quantile(cyc, torch.tensor([0.5, 0.9, 0.99, 1.0], device="cuda"))
+    worst = int(cyc.argmax()); print("cycles median/p90/p99/max", qc.tolist(), "worst env expansions", ex[worst].item(), "path", pl[worst].item(), "corr", torch.corrcoef(torch.stack((cyc, ex)))[0,1].item())
+    print(f"replan launch {e0.elapsed_time(e1)*1e3:.1f} us; expansions median/p90/p99/max = {q.tolist()}; path_len mean {pl.mean():.1f} min {pl.min()}, #len1 {(pl<2).sum().item()}")
