@@ -32,9 +32,10 @@ def algorithmic_bytes_per_env_step(P, W, H, O):
 
 
 def measure_env_tick(trainer, n_ticks):
-    """Average duration of the fused env-tick launch (HIP events on the launch stream), random actions, policy excluded."""
+    """Launch durations of the fused env tick (HIP events on the launch stream; random actions, policy excluded):
+    the regular tick k_tick<step,observe,evader> and the replan variant that runs every `difficulty` ticks."""
     env = trainer.env
-    N, P = env.num_envs, env.num_defender
+    N, P, D = env.num_envs, env.num_defender, env.pe_cfg.difficulty
     env.reset()
     obs = env.sim.new_obs()
     reward = torch.zeros((N, P), dtype=torch.float32, device=trainer.device)
@@ -42,13 +43,31 @@ def measure_env_tick(trainer, n_ticks):
     env.observe(obs)
     env.attacker_step()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_ticks + 1)]
+    ev[0].record()
+    kinds = []
     for t in range(n_ticks):
         env.tick(acts[t], obs, reward)
-    e1.record()
+        kinds.append(env.sim.t_host % D == 0)
+        ev[t + 1].record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n_ticks * 1e-3  # seconds per launch
+    dur = [ev[t].elapsed_time(ev[t + 1]) * 1e-3 for t in range(n_ticks)]
+    reg = [d for d, k in zip(dur, kinds) if not k]
+    rep = [d for d, k in zip(dur, kinds) if k]
+    return sum(reg) / max(1, len(reg)), (sum(rep) / len(rep) if rep else float("nan")), sum(dur) / n_ticks
+
+
+def load_pmc_traffic(N):
+    """HBM bytes per launch of the regular tick from the committed rocprofv3 PMC passes (profiles/r01_tick_pmc.json,
+    produced with tools/profile_tick.py; FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as read)."""
+    path = os.path.join(ROOT, "profiles", "r01_tick_pmc.json")
+    try:
+        j = json.load(open(path))
+        if j.get("num_envs") == N:
+            return j["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(cfg, n_envs, T, threads):
@@ -155,18 +174,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=tr.device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tr.device if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     rollout_ms, update_ms = tr.last_breakdown_ms()
     # roofline of the environment tick kernel: algorithmic bytes / measured launch duration
-    t_tick = measure_env_tick(tr, args.tick_samples)
+    t_tick, t_replan, t_avg = measure_env_tick(tr, args.tick_samples)
     bytes_per_step = algorithmic_bytes_per_env_step(P, W, H, O)
     achieved = N * bytes_per_step / t_tick / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_tick<step,observe,evader> (csrc/pe_env.hip)", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "bytes_per_env_step": bytes_per_step, "us_per_launch": round(t_tick * 1e6, 2), "env_steps_per_launch": N}
+    roofline = {"bound": "hbm", "kernel": "k_tick<step,observe,evader,no-replan> (csrc/pe_env.hip)", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": load_pmc_traffic(N) if args.config in ("cfg2", "cfg3") else None,
+                "bytes_per_env_step": bytes_per_step, "us_per_launch": round(t_tick * 1e6, 2), "env_steps_per_launch": N,
+                "replan_tick_us_per_launch": round(t_replan * 1e6, 2), "episode_avg_tick_us": round(t_avg * 1e6, 2)}
 
     out = None
     if rank == 0:

@@ -29,7 +29,7 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("DMARL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -39,7 +39,12 @@ def init_distributed(backend=None):
 def allreduce_sum_(flat):
     """gradient SUM over learners (main.py:121-126); no-op on one rank"""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() == "gloo":  # rehearsal of the N > 1 path on one GPU: stage through the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
@@ -64,7 +69,12 @@ def broadcast_weights_(modules, src=0):
             for t in list(m.parameters()) + list(m.buffers()):
                 if id(t) not in seen:
                     seen.add(id(t))
-                    dist.broadcast(t.data, src=src)
+                    if t.is_cuda and dist.get_backend() == "gloo":
+                        host = t.data.cpu()
+                        dist.broadcast(host, src=src)
+                        t.data.copy_(host)
+                    else:
+                        dist.broadcast(t.data, src=src)
 
 
 def save_checkpoint(actor, critic, cwd, suffix=""):
@@ -87,7 +97,7 @@ class Trainer:
     def __init__(self, cfg, num_envs=None, mini_batch_size=None):
         self.rank, self.local_rank, self.world = init_distributed()
         self.cfg = cfg
-        self.device = torch.device("cuda", self.local_rank if torch.cuda.device_count() > 1 else 0)
+        self.device = torch.device("cuda", self.local_rank % max(1, torch.cuda.device_count()))
         torch.cuda.set_device(self.device)
         self.num_envs = int(num_envs if num_envs is not None else cfg.runtime.num_envs)
         epi = int(cfg.algo.sample_epi_num)
@@ -150,7 +160,7 @@ def train_agent_multiprocessing(cfg, max_iterations=None, num_eval_envs=16, eval
                     draw_learning_curve(recorder=np.array(recorder), cwd=cwd)
                     save_checkpoint(actor, critic, cwd)
         if tr.world > 1:
-            flag = torch.tensor([1 if if_train else 0], device=tr.device)
+            flag = torch.tensor([1 if if_train else 0], device=tr.device if dist.get_backend() != "gloo" else "cpu")
             dist.broadcast(flag, src=0)
             if_train = bool(flag.item())
         if max_iterations is not None and tr.iteration >= max_iterations:

@@ -1,0 +1,84 @@
+"""GPU tests of the reference-API layer (Learner / Worker / EvaluatorProc / trainer) and of a 2-rank rehearsal."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import ROOT
+from tests.helpers import product_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def small_cfg(tmp_path, **extra):
+    return product_cfg(4, 20, 20, T=10, depth=1, blocks=2, variance=4,
+                       **{"algo.save_cwd": str(tmp_path / "model"), "algo.max_train_steps": 2000, "runtime.num_envs": 8, **extra})
+
+
+def test_reference_protocol_worker_learner(tmp_path):
+    """main.py:79-132 with .remote() removed: weights down, buffers up, gradient lists summed over learners, same update."""
+    from distributed_multi_agent_reinforcement_learning_amd.runner import Learner, Worker
+    cfg = small_cfg(tmp_path)
+    torch.manual_seed(0)
+    learners = [Learner(cfg, 8, 4, i) for i in range(2)]
+    workers = [Worker(i, cfg, num_envs=8) for i in range(2)]
+    aw, cw = learners[0].get_weights()
+    for lr in learners:
+        lr.set_weights(aw, cw)
+    total = 0
+    for lr, wk in zip(learners, workers):
+        exp_r, steps = lr.collect_buffer([wk.run(aw, cw)])
+        assert steps == 8 * 10
+        total += steps
+    grads = [lr.compute_and_get_gradients(total) for lr in learners]
+    a_sum = [np.stack(g).sum(0) for g in zip(*[g[1] for g in grads])]
+    c_sum = [np.stack(g).sum(0) for g in zip(*[g[2] for g in grads])]
+    for lr in learners:
+        lr.set_gradients_and_update(a_sum, c_sum, total)
+    w0, w1 = learners[0].get_weights(), learners[1].get_weights()
+    for k in w0[0]:
+        assert torch.equal(w0[0][k], w1[0][k]), k          # identical update on every learner
+        if "weight" in k and "GRU" in k:
+            assert not torch.equal(w0[0][k], aw[k])        # and the weights moved
+    assert len(grads[0][1]) == len(list(learners[0].agent.actor.parameters()))
+    # two workers with different ranks explore different maps
+    assert not torch.equal(workers[0].env.sim.grid, workers[1].env.sim.grid)
+
+
+def test_training_loop_checkpoints_and_recorder(tmp_path):
+    from distributed_multi_agent_reinforcement_learning_amd import trainer
+    from distributed_multi_agent_reinforcement_learning_amd.model import build_actor_critic
+    cfg = small_cfg(tmp_path)
+    tr = trainer.train_agent_multiprocessing(cfg, max_iterations=2, num_eval_envs=4)
+    cwd = cfg.algo.save_cwd
+    for name in ("actor", "critic", "actor_gnn", "critic_gnn", "actor_gru", "critic_gru", "actor_mean", "critic_mean"):
+        assert os.path.exists(f"{cwd}/{name}_final.pth"), name
+    rec = np.load(cwd + "/recorder.npy")
+    assert rec.shape[1] == 6 and rec.shape[0] >= 1             # (total_step, avg_r, std_r, exp_r, objC, objA)
+    assert os.path.exists(cwd + "/learning_curve.jpg")
+    sd = torch.load(cwd + "/state_dicts_final.pt", weights_only=True)
+    actor, critic = build_actor_critic(cfg, "cpu")
+    actor.load_state_dict(sd["actor"]); critic.load_state_dict(sd["critic"])
+    whole = torch.load(cwd + "/actor_final.pth", weights_only=False)
+    assert list(whole.state_dict().keys()) == list(actor.state_dict().keys())
+    assert tr.total_steps == 2 * 8 * 10
+
+
+def test_two_rank_bench_rehearsal(tmp_path):
+    """bench.py under torch.distributed.run with 2 ranks sharing the one GPU (gloo stands in for RCCL): the N > 1 path
+    -- shard seeds per rank, gradient all-reduce, max-over-ranks timing, one JSON line from rank 0 -- runs end to end."""
+    env = dict(os.environ, DMARL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "cfg1",
+           "--num-envs", "16", "--max-steps", "12", "--tick-samples", "12"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert abs(j["value"] - 2 * 16 * 12 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
