@@ -18,6 +18,24 @@ from .mappo import MAPPO
 from .pursuit_env import Pursuit_Env
 
 
+TUNED_GEMM_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+
+
+def enable_tuned_gemms(path=TUNED_GEMM_FILE):
+    """Library GEMM solution selection (PyTorch TunableOp over rocBLAS / hipBLASLt) from the committed tuning file
+    produced by tools/tune_gemms.py; nothing is tuned at run time.  Returns True when the file was loaded."""
+    if os.environ.get("DMARL_TUNED_GEMMS", "1") == "0" or not os.path.exists(path) or not torch.cuda.is_available():
+        return False
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.set_filename(path, insert_device_ordinal=False)
+        return bool(tunable.read_file(path))
+    except Exception:
+        return False
+
+
 def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
@@ -94,8 +112,9 @@ def save_checkpoint(actor, critic, cwd, suffix=""):
 class Trainer:
     """One rank of the data-parallel job."""
 
-    def __init__(self, cfg, num_envs=None, mini_batch_size=None):
+    def __init__(self, cfg, num_envs=None, mini_batch_size=None, tuned_gemms=True):
         self.rank, self.local_rank, self.world = init_distributed()
+        self.tuned_gemms = enable_tuned_gemms() if tuned_gemms else False
         self.cfg = cfg
         self.device = torch.device("cuda", self.local_rank % max(1, torch.cuda.device_count()))
         torch.cuda.set_device(self.device)
