@@ -17,6 +17,7 @@ struct MsgArgs {
     int R, P, K, E, din, q_div, adj_mode;
     const float *p, *q, *e, *adj;
     int64_t p_rs, q_rs, e_rs, adj_rs;  // row strides in elements (rows may be slices of (N, T, ...) buffers)
+    int64_t o_is;                       // elements between consecutive (row, agent) vectors of out / gout
     const int32_t *kvalid;
     const float *W, *b;
 };
@@ -125,7 +126,7 @@ __global__ void k_msg_agg_fwd(MsgArgs a, float *out) {
         }
 #pragma unroll
         for (int i = 0; i < PT; i++)
-            if (i < P) out[((size_t)r * P + i) * E + f] = acc[i] * l.inv[i];
+            if (i < P) out[((size_t)r * P + i) * a.o_is + f] = acc[i] * l.inv[i];
         __syncthreads();
     }
 }
@@ -154,7 +155,7 @@ __global__ void k_msg_agg_bwd(MsgArgs a, const float *gout, float *partials) {
             if (i < P) {
                 c[i] = bias + w[0] * l.p[i * 4] + w[1] * l.p[i * 4 + 1] + w[2] * l.p[i * 4 + 2] + w[3] * l.p[i * 4 + 3];
                 if (a.din == 8) c[i] += w[4] * l.pe[i * 4] + w[5] * l.pe[i * 4 + 1] + w[6] * l.pe[i * 4 + 2] + w[7] * l.pe[i * 4 + 3];
-                gi[i] = gout[((size_t)r * P + i) * E + f] * l.inv[i];
+                gi[i] = gout[((size_t)r * P + i) * a.o_is + f] * l.inv[i];
             }
         }
         float hq0 = 0.f, hq1 = 0.f, hq2 = 0.f, hq3 = 0.f;
@@ -391,12 +392,12 @@ extern "C" {
 
 int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
                      int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const float *adj, int64_t adj_rs, int32_t adj_mode,
-                     const int32_t *kvalid, const float *W, const float *b, float *out, void *stream) {
+                     const int32_t *kvalid, const float *W, const float *b, float *out, int64_t out_stride, void *stream) {
     int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
     if (rc) return rc;
     if (R == 0) return 0;
-    if (q_rs & 3) return MO_ERR_BAD_ARG;
-    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, p_rs, q_rs, e_rs, adj_rs, kvalid, W, b};
+    if ((q_rs & 3) || out_stride < E) return MO_ERR_BAD_ARG;
+    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, p_rs, q_rs, e_rs, adj_rs, out_stride, kvalid, W, b};
     const int grid = R < 8192 ? R : 8192;
     if (P <= 4) hipLaunchKernelGGL(k_msg_agg_fwd<4>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
     else if (P <= 8) hipLaunchKernelGGL(k_msg_agg_fwd<8>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
@@ -408,13 +409,13 @@ int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD
 
 int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
                      int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const float *adj, int64_t adj_rs, int32_t adj_mode,
-                     const int32_t *kvalid, const float *W, const float *b, const float *gout, float *dW, float *db,
+                     const int32_t *kvalid, const float *W, const float *b, const float *gout, int64_t gout_stride, float *dW, float *db,
                      void *workspace, void *stream) {
     int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
     if (rc) return rc;
     if (!workspace || !gout || !dW || !db) return MO_ERR_BAD_ARG;
-    if (q_rs & 3) return MO_ERR_BAD_ARG;
-    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, p_rs, q_rs, e_rs, adj_rs, kvalid, W, b};
+    if ((q_rs & 3) || gout_stride < E) return MO_ERR_BAD_ARG;
+    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, p_rs, q_rs, e_rs, adj_rs, gout_stride, kvalid, W, b};
     const int grid = R < BWD_BLOCKS ? (R > 0 ? R : 1) : BWD_BLOCKS;
     if (P <= 4) hipLaunchKernelGGL(k_msg_agg_bwd<4>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);
     else if (P <= 8) hipLaunchKernelGGL(k_msg_agg_bwd<8>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);

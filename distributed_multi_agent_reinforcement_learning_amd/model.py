@@ -64,29 +64,30 @@ class DHGN(nn.Module):
         """p (R,P,4), e (R,1,4), o (R/q_div,O,4), adj_* (R,P,{P,1,O}) -> h0 (R,P,E).
         is_critic: adjacency := ones (AttributeDataset, :64-65); in a batched rollout the obstacle relation uses ones
         over the first o_kvalid[row] (real) obstacles, in training over all padded slots."""
-        e2 = e.reshape(e.shape[0], 4)
-        mode = ops.ADJ_ONES if is_critic else ops.ADJ_TENSOR
-        m0 = ops.msg_agg(p, p, e2, adj_p, self.MSG_layers[0].weight, self.MSG_layers[0].bias, mode)
-        m1 = ops.msg_agg(p, e, None, adj_e, self.MSG_layers[1].weight, self.MSG_layers[1].bias, mode)
-        mode_o = mode
-        if is_critic and o_kvalid is not None:
-            mode_o = ops.ADJ_VALID
-        m2 = ops.msg_agg(p, o, None, adj_o, self.MSG_layers[2].weight, self.MSG_layers[2].bias, mode_o, o_kvalid, q_div)
-        emb = F.relu(self.AGG_layers["AGG_vertex_0"](torch.stack((m0, m1, m2), 0)))
-        x = torch.cat((p, emb[0], emb[1], emb[2]), dim=-1)
-        return self.semantic_layer(x)
+        R, P = p.shape[0], p.shape[1]
+        E, ind = self.embedding_dim, self.input_dim
+        M = self.MSG_layers
+        m3 = ops.msg_agg3(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
+                          is_critic, o_kvalid, q_div)                                  # (R, P, 3, E)
+        emb = F.relu(self.AGG_layers["AGG_vertex_0"](m3))                             # one GEMM for the three relations
+        # semantic_layer([p, emb0, emb1, emb2]) without materialising the concatenation (:284-303)
+        Ws = self.semantic_layer.weight
+        h0 = F.linear(emb.reshape(R * P, 3 * E), Ws[:, ind:]) + F.linear(p.reshape(R * P, ind), Ws[:, :ind], self.semantic_layer.bias)
+        return h0.reshape(R, P, E)
 
     # -- fixed-depth recursive aggregation over neighbours' historical embeddings (:204-233) --------------
     def fcra(self, h0, hist, adj_p, is_critic):
         """hist: sequence of `depth` tensors (R,P,E), hop k = hist[k] (k = 0 is the most recent)."""
         h = h0
+        E = self.embedding_dim
         if self.depth == 0:
             return h
         adj = torch.ones_like(adj_p) if is_critic else adj_p
         abar = F.normalize(adj, p=1, dim=-1)
         for k in range(self.depth):
             agg = F.relu(self.AGG_layers[f"AGG_fcra_{k}"](torch.matmul(abar, hist[k])))
-            h = F.relu(self.FCRA_layers[k](torch.cat((agg, h), dim=-1)))
+            Wf = self.FCRA_layers[k].weight  # FCRA_k([agg, h]) as two accumulating GEMMs instead of a concatenation
+            h = F.relu(F.linear(agg, Wf[:, :E]) + F.linear(h, Wf[:, E:], self.FCRA_layers[k].bias))
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1):

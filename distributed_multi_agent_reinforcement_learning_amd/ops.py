@@ -31,8 +31,8 @@ def load_library():
                                "the fused MAPPO ops have no fallback")
         L = C.CDLL(path)
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-        L.dhgn_msg_agg_fwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp]
-        L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.dhgn_msg_agg_fwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp]
+        L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
         L.dhgn_msg_agg_bwd_workspace.restype = i64
         L.gae_advnorm.argtypes = [i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
@@ -81,28 +81,38 @@ def _workspace(device, E, din):
     return ws
 
 
+def _msg_call(kind, L, p, q, e, adj, kvalid, W, b, adj_mode, q_div, io, io_stride, extra=()):
+    """one relation: io = out (fwd) or gout (bwd) slot pointer with io_stride elements between [E] vectors"""
+    R, P = p.shape[0], p.shape[1]
+    K = q.shape[1]
+    E, din = W.shape
+    assert p.dtype == torch.float32 and p.shape[2] == 4 and _rows_ok(p)
+    assert _rows_ok(q) and q.shape[2] == 4 and q.shape[0] * q_div == R and q.stride(0) % 4 == 0
+    if adj_mode == ADJ_TENSOR:
+        assert adj.shape == (R, P, K) and adj.dtype == torch.float32 and _rows_ok(adj)
+    if e is not None:
+        assert e.shape == (R, 4) and _rows_ok(e)
+    if adj_mode == ADJ_VALID:
+        assert kvalid.dtype == torch.int32 and kvalid.is_contiguous() and kvalid.shape[0] * q_div == R
+    args = (R, P, K, E, din, _ptr(p), p.stride(0), _ptr(q), q.stride(0), q_div, _ptr(e), e.stride(0) if e is not None else 0,
+            _ptr(adj) if adj_mode == ADJ_TENSOR else None, adj.stride(0) if adj_mode == ADJ_TENSOR else 0, adj_mode,
+            _ptr(kvalid) if adj_mode == ADJ_VALID else None, _ptr(W), _ptr(b), io, io_stride)
+    if kind == "fwd":
+        _check(L.dhgn_msg_agg_fwd(*args, _stream()), "dhgn_msg_agg_fwd")
+    else:
+        _check(L.dhgn_msg_agg_bwd(*args, *extra, _stream()), "dhgn_msg_agg_bwd")
+
+
 class _MsgAgg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, q, e, adj, kvalid, W, b, adj_mode, q_div):
         L = load_library()
         _need_gpu(p, "dhgn_msg_agg")
         R, P = p.shape[0], p.shape[1]
-        K = q.shape[1]
-        E, din = W.shape
-        assert p.dtype == torch.float32 and p.shape[2] == 4 and _rows_ok(p)
-        assert _rows_ok(q) and q.shape[2] == 4 and q.shape[0] * q_div == R and q.stride(0) % 4 == 0
-        if adj is not None:
-            assert adj.shape == (R, P, K) and adj.dtype == torch.float32 and _rows_ok(adj)
-        if e is not None:
-            assert e.shape == (R, 4) and _rows_ok(e)
-        ctx.strides = (p.stride(0), q.stride(0), e.stride(0) if e is not None else 0, adj.stride(0) if adj is not None else 0)
-        if kvalid is not None:
-            assert kvalid.dtype == torch.int32 and kvalid.is_contiguous() and kvalid.shape[0] * q_div == R
+        E = W.shape[0]
         Wc, bc = W.detach().contiguous(), b.detach().contiguous()
         out = torch.empty((R, P, E), dtype=torch.float32, device=p.device)
-        ps, qs, es, as_ = ctx.strides
-        _check(L.dhgn_msg_agg_fwd(R, P, K, E, din, _ptr(p), ps, _ptr(q), qs, q_div, _ptr(e), es, _ptr(adj), as_, adj_mode,
-                                  _ptr(kvalid), _ptr(Wc), _ptr(bc), _ptr(out), _stream()), "dhgn_msg_agg_fwd")
+        _msg_call("fwd", L, p, q, e, adj, kvalid, Wc, bc, adj_mode, q_div, _ptr(out), E)
         ctx.save_for_backward(p, q, e, adj, kvalid, Wc, bc)
         ctx.meta = (adj_mode, q_div)
         return out
@@ -112,17 +122,11 @@ class _MsgAgg(torch.autograd.Function):
         L = load_library()
         p, q, e, adj, kvalid, W, b = ctx.saved_tensors
         adj_mode, q_div = ctx.meta
-        R, P = p.shape[0], p.shape[1]
-        K = q.shape[1]
         E, din = W.shape
         gout = gout.contiguous()
-        dW = torch.empty_like(W)
-        db = torch.empty_like(b)
+        dW, db = torch.empty_like(W), torch.empty_like(b)
         ws = _workspace(p.device, E, din)
-        ps, qs, es, as_ = ctx.strides
-        _check(L.dhgn_msg_agg_bwd(R, P, K, E, din, _ptr(p), ps, _ptr(q), qs, q_div, _ptr(e), es, _ptr(adj), as_, adj_mode,
-                                  _ptr(kvalid), _ptr(W), _ptr(b), _ptr(gout), _ptr(dW), _ptr(db), _ptr(ws), _stream()),
-               "dhgn_msg_agg_bwd")
+        _msg_call("bwd", L, p, q, e, adj, kvalid, W, b, adj_mode, q_div, _ptr(gout), E, (_ptr(dW), _ptr(db), _ptr(ws)))
         return None, None, None, None, None, dW, db, None, None
 
 
@@ -132,6 +136,54 @@ def msg_agg(p, q, e, adj, W, b, adj_mode=ADJ_TENSOR, kvalid=None, q_div=1):
     adj (R,P,K)|None -> (R,P,E)."""
     return _MsgAgg.apply(p, q, e, adj if adj_mode == ADJ_TENSOR else None, kvalid if adj_mode == ADJ_VALID else None, W, b,
                          adj_mode, q_div)
+
+
+class _MsgAgg3(torch.autograd.Function):
+    """The three relations of DHGN.encoder in one autograd node writing one (R, P, 3, E) tensor (relation r in slot r), so
+    the shared AGG_vertex_0 layer runs as a single GEMM on a view and no stack / concatenate copies exist."""
+
+    @staticmethod
+    def forward(ctx, p, e, o, adj_p, adj_e, adj_o, kvalid, W0, b0, W1, b1, W2, b2, mode, mode_o, q_div):
+        L = load_library()
+        _need_gpu(p, "dhgn_msg_agg")
+        R, P = p.shape[0], p.shape[1]
+        E = W0.shape[0]
+        ws = [t.detach().contiguous() for t in (W0, b0, W1, b1, W2, b2)]
+        e2 = e.reshape(R, 4)
+        out = torch.empty((R, P, 3, E), dtype=torch.float32, device=p.device)
+        slot = lambda r: C.c_void_p(out.data_ptr() + 4 * r * E)
+        _msg_call("fwd", L, p, p, e2, adj_p, None, ws[0], ws[1], mode, 1, slot(0), 3 * E)
+        _msg_call("fwd", L, p, e, None, adj_e, None, ws[2], ws[3], mode, 1, slot(1), 3 * E)
+        _msg_call("fwd", L, p, o, None, adj_o, kvalid, ws[4], ws[5], mode_o, q_div, slot(2), 3 * E)
+        ctx.save_for_backward(p, e, o, adj_p, adj_e, adj_o, kvalid, *ws)
+        ctx.meta = (mode, mode_o, q_div)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = load_library()
+        p, e, o, adj_p, adj_e, adj_o, kvalid, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
+        mode, mode_o, q_div = ctx.meta
+        R = p.shape[0]
+        E = W0.shape[0]
+        gout = gout.contiguous()
+        slot = lambda r: C.c_void_p(gout.data_ptr() + 4 * r * E)
+        grads = []
+        for r, (q, ee, adj, kv, W, b, m, qd) in enumerate(((p, e.reshape(R, 4), adj_p, None, W0, b0, mode, 1), (e, None, adj_e, None, W1, b1, mode, 1),
+                                                           (o, None, adj_o, kvalid, W2, b2, mode_o, q_div))):
+            dW, db = torch.empty_like(W), torch.empty_like(b)
+            ws = _workspace(p.device, E, W.shape[1])
+            _msg_call("bwd", L, p, q, ee, adj, kv, W, b, m, qd, slot(r), 3 * E, (_ptr(dW), _ptr(db), _ptr(ws)))
+            grads += [dW, db]
+        return (None,) * 7 + tuple(grads) + (None, None, None)
+
+
+def msg_agg3(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, is_critic, o_kvalid=None, q_div=1):
+    """(R, P, 3, E): the message/aggregate of the defender, evader and obstacle relation (DHGN/mappo_parallel.py:256-281)."""
+    mode = ADJ_ONES if is_critic else ADJ_TENSOR
+    mode_o = ADJ_VALID if (is_critic and o_kvalid is not None) else mode
+    return _MsgAgg3.apply(p, e, o, adj_p, adj_e, adj_o, o_kvalid if mode_o == ADJ_VALID else None, W0, b0, W1, b1, W2, b2, mode,
+                          mode_o, q_div)
 
 
 def gae_advnorm(r, v, active, gamma, lamda, use_adv_norm=True):

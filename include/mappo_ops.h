@@ -31,12 +31,13 @@ enum { MO_ADJ_TENSOR = 0,   /* actor: the observed adjacency                    
  *   p [R][P][4] (rows p_row_stride elements apart, likewise e and adj: rows may be slices buffer[:, t] of (N,T,..)
  *   replay-buffer tensors); q [R/q_div][K][4] (q_div p-rows share one q-row: obstacles are static over an episode);
  *   e [R][4] or NULL (din == 4); adj [R][P][K] (MO_ADJ_TENSOR) ; kvalid [R/q_div] (MO_ADJ_VALID);
- *   W [E][din]; b [E]; out [R][P][E].
+ *   W [E][din]; b [E]; out [R][P][E] with out_stride elements between consecutive [E] vectors (out_stride = 3E
+ *   writes relation r of an [R][P][3][E] tensor when out points at slot r).
  */
 int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_row_stride,
                      const float *q, int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const float *adj,
                      int64_t adj_row_stride, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
-                     float *out, void *stream);
+                     float *out, int64_t out_stride /* elements between consecutive (row, agent) vectors, >= E */, void *stream);
 
 /*
  * Backward of the above w.r.t. W and b (the inputs are data, they carry no gradient): recomputes the
@@ -48,7 +49,7 @@ int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din);
 int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_row_stride,
                      const float *q, int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const float *adj,
                      int64_t adj_row_stride, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
-                     const float *gout, float *dW, float *db, void *workspace, void *stream);
+                     const float *gout, int64_t gout_stride, float *dW, float *db, void *workspace, void *stream);
 
 /*
  * GAE reverse scan + value target + advantage normalisation (DHGN/mappo_parallel.py:643-658):
