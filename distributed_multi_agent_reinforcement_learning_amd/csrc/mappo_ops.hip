@@ -372,6 +372,154 @@ __global__ void k_gru_gates_bwd(int B, int H, const float *dout, const float *dc
     *(float4 *)(dhdirect + o) = dd;
 }
 
+// ---- persistent GRU over a whole sequence (H = 128) ---------------------------------------------------------------
+// The recurrence h_t = cell(gi_t, h_{t-1}) is latency bound when every step is a GEMM launch plus a gate launch
+// (2 x 150 launches per layer, ~27 us per step at 3280 rows).  Here one workgroup (8 wavefronts) owns 16 batch rows for
+// all T steps: W_hh (384 x 128 fp32 = 196 KB, more than LDS) lives in the workgroup's REGISTERS -- wave w holds the
+// r/z/n rows of hidden units 16w..16w+15 as v_mfma_f32_16x16x4_f32 B-operands (96 VGPRs) -- the h tile lives in LDS in
+// A-operand order, the three gate tiles of a hidden unit land in the same lane (C layout: col = lane & 15,
+// row = 4 (lane >> 4) + reg), so the gate math needs no exchange and there is one barrier per step.
+constexpr int GRU_H = 128, GRU_RB = 16, GRU_LD = 36;  // LD: 32 k-groups + 4 pad floats (bank spread for ds_read_b128)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int gru_hidx(int row, int k) { return ((k & 3) * GRU_RB + row) * GRU_LD + (k >> 2); }
+
+__global__ __launch_bounds__(512) void k_gru_seq_fwd(int T, int B, const float *gi, const float *w_hh, const float *b_hh, const float *h0,
+                                                     float *out, float *save) {
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * GRU_RB * GRU_LD];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int b0 = blockIdx.x * GRU_RB;
+    const int c16 = l & 15, q = l >> 4;
+    const int j = 16 * w + c16;  // hidden unit of this lane's C columns
+    float wr[32], wz[32], wn[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; kk++) {
+        wr[kk] = w_hh[(size_t)(j) * GRU_H + 4 * kk + q];
+        wz[kk] = w_hh[(size_t)(GRU_H + j) * GRU_H + 4 * kk + q];
+        wn[kk] = w_hh[(size_t)(2 * GRU_H + j) * GRU_H + 4 * kk + q];
+    }
+    const float br = b_hh[j], bz = b_hh[GRU_H + j], bn = b_hh[2 * GRU_H + j];
+    for (int e = tid; e < GRU_RB * GRU_H; e += 512) {
+        const int row = e >> 7, k = e & 127;
+        hs[0][gru_hidx(row, k)] = (b0 + row < B) ? h0[(size_t)(b0 + row) * GRU_H + k] : 0.f;
+    }
+    __syncthreads();
+    int cur = 0;
+    const size_t BH = (size_t)B * GRU_H;
+    for (int t = 0; t < T; t++) {
+        float gir[4], giz[4], gin[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = 4 * q + reg;
+            gir[reg] = giz[reg] = gin[reg] = 0.f;
+            if (b0 + row < B) {
+                const float *g = gi + ((size_t)t * B + b0 + row) * 3 * GRU_H;
+                gir[reg] = g[j]; giz[reg] = g[GRU_H + j]; gin[reg] = g[2 * GRU_H + j];
+            }
+        }
+        const float *hp = &hs[cur][(q * GRU_RB + c16) * GRU_LD];  // A operand: row = lane & 15, k = 4 kk + (lane >> 4)
+        f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; k4++) {
+            const f32x4 a = *(const f32x4 *)(hp + 4 * k4);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], wr[4 * k4 + u], ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], wz[4 * k4 + u], az, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], wn[4 * k4 + u], an, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = 4 * q + reg;
+            const int hi = gru_hidx(row, j);
+            const float hprev = hs[cur][hi];
+            const float r = sigmoidf_(gir[reg] + ar[reg] + br);
+            const float z = sigmoidf_(giz[reg] + az[reg] + bz);
+            const float hn = an[reg] + bn;
+            const float n = tanhf(gin[reg] + r * hn);
+            const float hnew = (1.f - z) * n + z * hprev;
+            hs[cur ^ 1][hi] = hnew;
+            if (b0 + row < B) {
+                const size_t o = (size_t)(b0 + row) * GRU_H + j;
+                out[(size_t)t * BH + o] = hnew;
+                if (save) {
+                    float *sv = save + (size_t)t * 4 * BH;
+                    sv[o] = r; sv[BH + o] = z; sv[2 * BH + o] = n; sv[3 * BH + o] = hn;
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// backward of the sequence: dgi, dgh [T][B][3H] for the later weight-gradient GEMMs, dh0 [B][H].
+// dL/dh_{t-1} = dh_t z_t + dgh_t W_hh : the (16 x 384) dgh tile goes through LDS in A-operand order, W_hh columns
+// 16w..16w+15 are the B-operand of wave w (96 VGPRs), and the result lands in the lane that owns that (row, hidden unit).
+constexpr int GRU_LD3 = 100;  // 96 k-groups + 4 pad
+__device__ __forceinline__ int gru_gidx(int row, int k) { return ((k & 3) * GRU_RB + row) * GRU_LD3 + (k >> 2); }
+
+__global__ __launch_bounds__(512) void k_gru_seq_bwd(int T, int B, const float *dout, const float *save, const float *out, const float *h0,
+                                                     const float *w_hh, float *dgi, float *dgh, float *dh0) {
+    __shared__ __attribute__((aligned(16))) float gs[4 * GRU_RB * GRU_LD3];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int b0 = blockIdx.x * GRU_RB;
+    const int c16 = l & 15, q = l >> 4;
+    const int j = 16 * w + c16;
+    float wb[96];
+#pragma unroll
+    for (int kk = 0; kk < 96; kk++) wb[kk] = w_hh[(size_t)(4 * kk + q) * GRU_H + j];  // B[k][n = j]
+    const size_t BH = (size_t)B * GRU_H;
+    float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = T - 1; t >= 0; t--) {
+        float dhz[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = 4 * q + reg;
+            float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f;
+            dhz[reg] = 0.f;
+            if (b0 + row < B) {
+                const size_t o = (size_t)(b0 + row) * GRU_H + j;
+                const float *sv = save + (size_t)t * 4 * BH;
+                const float r = sv[o], z = sv[BH + o], n = sv[2 * BH + o], hn = sv[3 * BH + o];
+                const float hp = t > 0 ? out[(size_t)(t - 1) * BH + o] : h0[o];
+                const float dh = dout[(size_t)t * BH + o] + dcarry[reg];
+                dn = dh * (1.f - z) * (1.f - n * n);
+                dz = dh * (hp - n) * z * (1.f - z);
+                dr = dn * hn * r * (1.f - r);
+                dnr = dn * r;
+                dhz[reg] = dh * z;
+                const size_t g = ((size_t)t * B + b0 + row) * 3 * GRU_H;
+                dgi[g + j] = dr; dgi[g + GRU_H + j] = dz; dgi[g + 2 * GRU_H + j] = dn;
+                dgh[g + j] = dr; dgh[g + GRU_H + j] = dz; dgh[g + 2 * GRU_H + j] = dnr;
+            }
+            gs[gru_gidx(row, j)] = dr; gs[gru_gidx(row, GRU_H + j)] = dz; gs[gru_gidx(row, 2 * GRU_H + j)] = dnr;
+        }
+        __syncthreads();
+        const float *gp = &gs[(q * GRU_RB + c16) * GRU_LD3];
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+        for (int k4 = 0; k4 < 24; k4 += 3) {
+            const f32x4 x0 = *(const f32x4 *)(gp + 4 * k4), x1 = *(const f32x4 *)(gp + 4 * k4 + 4), x2 = *(const f32x4 *)(gp + 4 * k4 + 8);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[u], wb[4 * k4 + u], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[u], wb[4 * k4 + 4 + u], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[u], wb[4 * k4 + 8 + u], a2, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) dcarry[reg] = dhz[reg] + (a0[reg] + a1[reg] + a2[reg]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int row = 4 * q + reg;
+        if (b0 + row < B) dh0[(size_t)(b0 + row) * GRU_H + j] = dcarry[reg];
+    }
+}
+
 size_t msg_lds_bytes(int P, int K) { return sizeof(float) * (size_t)(K * 4 + ((P * K + 3) & ~3) + P * 4 + P * 4 + MAX_P + K + 4); }
 
 int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, const void *adj, const void *kvalid, const void *e) {
@@ -467,6 +615,21 @@ int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, 
     const int n = B * (H >> 2);
     hipLaunchKernelGGL(k_gru_gates_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, H, dout, dcarry, save, h_prev, dgi, dgh,
                        dh_direct);
+    return (int)hipGetLastError();
+}
+
+int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
+                float *save, void *stream) {
+    if (T < 1 || B < 1 || H != GRU_H || !gi || !w_hh || !b_hh || !h0 || !out) return MO_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_gru_seq_fwd, dim3((B + GRU_RB - 1) / GRU_RB), dim3(512), 0, (hipStream_t)stream, T, B, gi, w_hh, b_hh, h0, out, save);
+    return (int)hipGetLastError();
+}
+
+int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0, const float *w_hh,
+                float *dgi, float *dgh, float *dh0, void *stream) {
+    if (T < 1 || B < 1 || H != GRU_H || !dout || !save || !out || !h0 || !w_hh || !dgi || !dgh || !dh0) return MO_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_gru_seq_bwd, dim3((B + GRU_RB - 1) / GRU_RB), dim3(512), 0, (hipStream_t)stream, T, B, dout, save, out, h0, w_hh, dgi,
+                       dgh, dh0);
     return (int)hipGetLastError();
 }
 

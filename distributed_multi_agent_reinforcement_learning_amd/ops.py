@@ -12,7 +12,7 @@ from . import build as _build
 
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
-           "gru_gates_fwd", "gru_gates_bwd",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_seq_fwd", "gru_seq_bwd",
            "mappo_ops_error_string")
 
 _lib = None
@@ -39,6 +39,8 @@ def load_library():
         L.categorical_sample.argtypes = [i32, i32, vp, C.c_uint64, C.c_uint64, i32, vp, vp, vp]
         L.gru_gates_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.gru_gates_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mappo_ops_error_string.argtypes = [C.c_int]
         L.mappo_ops_error_string.restype = C.c_char_p
         _lib = L
@@ -216,6 +218,9 @@ def categorical_sample(probs, seed, offset, greedy=False):
     return action.reshape(shape), logp.reshape(shape)
 
 
+PERSISTENT_GRU_MIN_T = 2  # sequences at least this long take the one-launch recurrence (H = 128)
+
+
 class _GRULayer(torch.autograd.Function):
     """One torch.nn.GRU layer over a sequence: the input projection and the recurrent projection are fp32 MFMA GEMMs
     (rocBLAS / hipBLASLt), the gate math between them is the fused HIP kernel pair gru_gates_{fwd,bwd}."""
@@ -232,11 +237,19 @@ class _GRULayer(torch.autograd.Function):
         out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
         need = any(ctx.needs_input_grad)
         save = torch.empty((T, 4, B, H), dtype=x.dtype, device=x.device) if need else None
+        b_hh = b_hh.contiguous()
+        st = _stream()
+        ctx.persistent = bool(H == 128 and T >= PERSISTENT_GRU_MIN_T)
+        if ctx.persistent:  # whole recurrence in one launch, W_hh in registers (csrc/mappo_ops.hip k_gru_seq_fwd)
+            whh = w_hh.detach().contiguous()
+            _check(L.gru_seq_fwd(T, B, H, _ptr(gi), _ptr(whh), _ptr(b_hh), _ptr(h0), _ptr(out), _ptr(save) if need else None, st),
+                   "gru_seq_fwd")
+            if need:
+                ctx.save_for_backward(x, h0, w_ih, whh, out, save)
+            return out
         gh = torch.empty((B, 3 * H), dtype=x.dtype, device=x.device)
         w_hh_t = w_hh.t()
-        b_hh = b_hh.contiguous()
         hprev = h0
-        st = _stream()
         for t in range(T):
             torch.mm(hprev, w_hh_t, out=gh)
             _check(L.gru_gates_fwd(B, H, _ptr(gi[t]), _ptr(gh), _ptr(b_hh), _ptr(hprev), _ptr(out[t]),
@@ -258,11 +271,16 @@ class _GRULayer(torch.autograd.Function):
         dh_direct = torch.empty((B, H), dtype=x.dtype, device=x.device)
         dcarry = None
         st = _stream()
-        for t in range(T - 1, -1, -1):
-            hprev = out[t - 1] if t > 0 else h0
-            _check(L.gru_gates_bwd(B, H, _ptr(dout[t]), _ptr(dcarry), _ptr(save[t]), _ptr(hprev), _ptr(dgi[t]), _ptr(dgh[t]),
-                                   _ptr(dh_direct), st), "gru_gates_bwd")
-            dcarry = torch.addmm(dh_direct, dgh[t], w_hh)
+        if ctx.persistent:
+            _check(L.gru_seq_bwd(T, B, H, _ptr(dout), _ptr(save), _ptr(out), _ptr(h0), _ptr(w_hh), _ptr(dgi), _ptr(dgh), _ptr(dh_direct), st),
+                   "gru_seq_bwd")
+            dcarry = dh_direct
+        else:
+            for t in range(T - 1, -1, -1):
+                hprev = out[t - 1] if t > 0 else h0
+                _check(L.gru_gates_bwd(B, H, _ptr(dout[t]), _ptr(dcarry), _ptr(save[t]), _ptr(hprev), _ptr(dgi[t]), _ptr(dgh[t]),
+                                       _ptr(dh_direct), st), "gru_gates_bwd")
+                dcarry = torch.addmm(dh_direct, dgh[t], w_hh)
         dgi2, dgh2 = dgi.reshape(T * B, 3 * H), dgh.reshape(T * B, 3 * H)
         dw_hh = torch.mm(dgh[0].t(), h0)
         if T > 1:

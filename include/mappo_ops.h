@@ -81,6 +81,18 @@ int gru_gates_fwd(int32_t B, int32_t H, const float *gi, const float *gh, const 
 int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, const float *save, const float *h_prev, float *dgi,
                   float *dgh, float *dh_direct, void *stream);
 
+/*
+ * Whole-sequence GRU layer in one persistent launch (H = 128 only): gi [T][B][3H] is the input projection
+ * x W_ih^T + b_ih (one MFMA GEMM), the recurrence over T runs inside the kernel with W_hh held in registers as
+ * v_mfma_f32_16x16x4_f32 operands and the h tile (16 batch rows per workgroup) in LDS.  out [T][B][H];
+ * save [T][4][B][H] (r, z, n, hn) or NULL.  The backward kernel consumes dout [T][B][H] (dL/d out) and produces
+ * dgi, dgh [T][B][3H] (inputs of the weight-gradient GEMMs) and dh0 [B][H].
+ */
+int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
+                float *save, void *stream);
+int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0,
+                const float *w_hh, float *dgi, float *dgh, float *dh0, void *stream);
+
 const char *mappo_ops_error_string(int code);
 
 #ifdef __cplusplus

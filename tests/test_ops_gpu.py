@@ -123,7 +123,7 @@ def test_categorical_sample_and_greedy():
     assert torch.allclose(freq, one, atol=5e-3)
 
 
-@pytest.mark.parametrize("T,B", [(1, 64), (9, 40)])
+@pytest.mark.parametrize("T,B", [(1, 64), (9, 40), (37, 333)])
 def test_fused_gru_matches_torch_gru(T, B):
     """ops.gru (MFMA GEMMs + fused gate kernels) == torch.nn.GRU on the CPU (fp32), outputs and all gradients."""
     from distributed_multi_agent_reinforcement_learning_amd import ops
