@@ -48,6 +48,7 @@ def load_config(path=None, **overrides):
     rt.setdefault("tape_len", 16)
     rt.setdefault("max_path", 128)
     rt.setdefault("reference_quirks", True)
+    rt.setdefault("use_graphs", True)
     for k, v in overrides.items():
         node = cfg
         parts = k.split(".")

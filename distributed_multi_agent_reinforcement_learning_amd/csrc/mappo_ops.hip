@@ -269,6 +269,8 @@ __global__ void k_gae_norm(int64_t n, float *adv, const float *active, const dou
     }
 }
 
+__global__ void k_advance_counter(uint64_t *ctr, uint64_t by) { *ctr += by; }
+
 // ---- Categorical sample / argmax ---------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *o) {
     for (int i = 0; i < 10; i++) {
@@ -280,9 +282,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-__global__ void k_categorical(int R, int A, const float *probs, uint64_t seed, uint64_t offset, int greedy, int32_t *action, float *logp) {
+__global__ void k_categorical(int R, int A, const float *probs, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, int greedy,
+                              int32_t *action, float *logp) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    if (offset_dev) offset += *offset_dev;
     const float *p = probs + (size_t)r * A;
     float tot = 0.f;
     for (int k = 0; k < A; k++) tot += p[k];
@@ -597,7 +601,18 @@ int categorical_sample(int32_t R, int32_t A, const float *probs, uint64_t seed, 
                        float *logp, void *stream) {
     if (R < 0 || A < 1 || !probs || !action) return MO_ERR_BAD_ARG;
     if (R == 0) return 0;
-    hipLaunchKernelGGL(k_categorical, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, A, probs, seed, offset, greedy, action, logp);
+    hipLaunchKernelGGL(k_categorical, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, A, probs, seed, offset,
+                       (const uint64_t *)nullptr, greedy, action, logp);
+    return (int)hipGetLastError();
+}
+
+int categorical_sample_counter(int32_t R, int32_t A, const float *probs, uint64_t seed, uint64_t *counter, int32_t greedy, int32_t *action,
+                               float *logp, void *stream) {
+    if (R < 0 || A < 1 || !probs || !action || !counter) return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(k_categorical, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, A, probs, seed, (uint64_t)0, counter, greedy,
+                       action, logp);
+    hipLaunchKernelGGL(k_advance_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, (uint64_t)R);
     return (int)hipGetLastError();
 }
 

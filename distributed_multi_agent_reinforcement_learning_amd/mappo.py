@@ -135,7 +135,7 @@ class MAPPO:
         rt = cfg.get("runtime", {})
         self.reference_quirks = bool(rt.get("reference_quirks", True))
         self.sample_seed = int(rt.get("seed", 0))
-        self.sample_offset = 0
+        self.use_graphs = bool(rt.get("use_graphs", True))
         self.last_adv = self.last_v_target = None
 
     # ---- update (:638-723) ------------------------------------------------------------------------------------
@@ -211,81 +211,163 @@ class MAPPO:
     @torch.no_grad()
     def run_episode(self, env, num_episode=0, actions_override=None, init=None):
         """N episodes in lockstep; rows [num_episode*N, (num_episode+1)*N) of the buffer.  Returns the per-environment
-        episode reward (N,) and the episode length."""
+        episode reward (N,) and the episode length.  The per-tick policy program (actor + critic forward, history
+        bookkeeping, sampling) runs on static device storage and is replayed as one captured hipGraph per tick
+        (`runtime.use_graphs`), which removes ~70 launches of host overhead per tick; the eager path executes the very same
+        program, so both produce identical buffers."""
         N, P, T, d = env.num_envs, env.num_defender, env.max_steps, self.depth
-        L, H, E = self.num_layers, self.rnn_hidden_dim, self.embedding_dim
-        dev = self.device
         buf = self.minibuffer.buffer
         rows = slice(num_episode * N, (num_episode + 1) * N)
         env.reset(init)
-        self.minibuffer.o_static[rows].copy_(env.boundary_map.obstacle_agent)
-        self.minibuffer.o_kvalid[rows].copy_(env.n_obs)
-        o_state, o_kvalid = self.minibuffer.o_static[rows], self.minibuffer.o_kvalid[rows]
-        ha = torch.zeros(L, N * P, H, device=dev)
-        hc = torch.zeros(L, N * P, H, device=dev)
-        shared = [torch.zeros(N, P, E, device=dev) for _ in range(d)]
-        a_hist = list(shared)
-        c_hist = list(shared)
-        a_cur = torch.zeros(N, P, E, device=dev)
-        c_cur = torch.zeros(N, P, E, device=dev)
-        episode_reward = torch.zeros(N, device=dev)
-        raw = torch.zeros(N, P, device=dev)
-
-        def obs_views(t):
-            return {k: buf[k][rows, t] for k in ("p_state", "e_state", "p_adj", "e_adj", "o_adj")}
-
-        env.observe(obs_views(0))
+        st = self._rollout_state(env)
+        st.reset(env)
+        self.minibuffer.o_static[rows].copy_(st.o_state)
+        self.minibuffer.o_kvalid[rows].copy_(st.o_kvalid)
+        episode_reward = torch.zeros(N, device=self.device)
+        raw = st.raw
+        obs_keys = ("p_state", "e_state", "p_adj", "e_adj", "o_adj")
+        env.observe(st.obs)
         env.attacker_step()
+        use_graph = self.use_graphs and actions_override is None
         for t in range(T):
-            o = obs_views(t)
-            o["o_state"] = o_state
-            o["o_kvalid"] = o_kvalid
-            if d:
-                if self.reference_quirks:  # one list serves both nets: (.., a_{t-1}, c_{t-1}) (SURVEY Q1)
-                    shared = (shared + [a_cur, c_cur])[-d:]
-                    hops_a = hops_c = [shared[d - 1 - k] for k in range(d)]
-                else:
-                    a_hist = (a_hist + [a_cur])[-d:]
-                    c_hist = (c_hist + [c_cur])[-d:]
-                    hops_a = [a_hist[d - 1 - k] for k in range(d)]
-                    hops_c = [c_hist[d - 1 - k] for k in range(d)]
-            else:
-                hops_a = hops_c = []
-            prob, ha, a_cur = self.actor(o, hops_a, ha, 0)
-            v_n, hc, c_cur = self.critic(o, hops_c, hc, 0, rollout=True)
+            for k in obs_keys:
+                buf[k][rows, t].copy_(st.obs[k])
             if actions_override is not None:
-                a_n = actions_override[rows, t].to(dev).long()
-                a_logprob = torch.distributions.Categorical(probs=prob).log_prob(a_n)
-                a_n = a_n.to(torch.int32)
+                st.policy_step(actions_override[rows, t].to(self.device).long())
+            elif use_graph:
+                st.replay_policy_step()
             else:
-                a_n, a_logprob = ops.categorical_sample(prob, self.sample_seed, self.sample_offset)
-                self.sample_offset += N * P
-            buf["actor_historical_embedding"][rows, t + d] = a_cur
-            buf["critic_historical_embedding"][rows, t + d] = c_cur
-            buf["v_n"][rows, t] = v_n.reshape(N, P)
-            buf["a_n"][rows, t] = a_n.float()
-            buf["a_logprob_n"][rows, t] = a_logprob
-            buf["active"][rows, t] = 1.0
+                st.policy_step()
+            buf["actor_historical_embedding"][rows, t + d].copy_(st.a_cur)
+            buf["critic_historical_embedding"][rows, t + d].copy_(st.c_cur)
+            buf["v_n"][rows, t].copy_(st.v)
+            buf["a_n"][rows, t].copy_(st.a_n)          # int32 -> float32 like the reference buffer
+            buf["a_logprob_n"][rows, t].copy_(st.logp)
             if t + 1 < T:
-                env.tick(a_n, obs_views(t + 1), buf["r"][rows, t], raw)
+                env.tick(st.a_n, st.obs, buf["r"][rows, t], raw)
             else:
-                env.sim.step(a_n, buf["r"][rows, t], raw)
+                env.sim.step(st.a_n, buf["r"][rows, t], raw)
                 env.time_step += 1
             episode_reward += raw.sum(-1)
+        buf["active"][rows].fill_(1.0)
         # bootstrap value of the state after the last step (:807-825): only the critic's embedding enters the history
-        fin = env.observe()
-        fin["o_state"], fin["o_kvalid"] = o_state, o_kvalid
-        if d:
-            if self.reference_quirks:
-                shared = (shared + [c_cur])[-d:]
-                hops_c = [shared[d - 1 - k] for k in range(d)]
-            else:
-                c_hist = (c_hist + [c_cur])[-d:]
-                hops_c = [c_hist[d - 1 - k] for k in range(d)]
-        v_n, hc, c_cur = self.critic(fin, hops_c, hc, 0, rollout=True)
-        buf["v_n"][rows, T] = v_n.reshape(N, P)
+        env.observe(st.obs)
+        st.value_step()
+        buf["v_n"][rows, T].copy_(st.v)
         return episode_reward, T
+
+    def _rollout_state(self, env):
+        st = getattr(self, "_rstate", None)
+        if st is None or st.N != env.num_envs:
+            st = _RolloutState(self, env)
+            self._rstate = st
+        return st
 
     def save_model(self, cwd):
         torch.save(self.actor.state_dict(), cwd + "actor.pth")
         torch.save(self.critic.state_dict(), cwd + "critic.pth")
+
+
+class _RolloutState:
+    """Static device storage of one lockstep rollout and the per-tick policy program on it."""
+
+    def __init__(self, agent, env):
+        self.agent = agent
+        N, P = env.num_envs, env.num_defender
+        O = env.pe_cfg.O
+        d, L, H, E = agent.depth, agent.num_layers, agent.rnn_hidden_dim, agent.embedding_dim
+        dev = agent.device
+        self.N, self.P, self.d = N, P, d
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.obs = dict(p_state=z(N, P, 4), e_state=z(N, 1, 4), p_adj=z(N, P, P), e_adj=z(N, P, 1), o_adj=z(N, P, O))
+        self.o_state = z(N, O, 4)
+        self.o_kvalid = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.ha, self.hc = z(L, N * P, H), z(L, N * P, H)
+        quirk = agent.reference_quirks
+        self.hist = z(max(d, 1), N, P, E)                    # shared list (SURVEY Q1), hop k = hist[k]
+        self.hist_c = None if quirk else z(max(d, 1), N, P, E)  # clean mode: actor uses hist, critic hist_c
+        self.a_cur, self.c_cur = z(N, P, E), z(N, P, E)
+        self.a_n = torch.zeros((N, P), dtype=torch.int32, device=dev)
+        self.logp, self.v, self.raw = z(N, P), z(N, P), z(N, P)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)   # position in the sampling stream (persists)
+        self.graph = None
+
+    def reset(self, env):
+        for t in (self.ha, self.hc, self.hist, self.a_cur, self.c_cur):
+            t.zero_()
+        if self.hist_c is not None:
+            self.hist_c.zero_()
+        self.o_state.copy_(env.boundary_map.obstacle_agent)
+        self.o_kvalid.copy_(env.n_obs)
+
+    def _obs(self):
+        o = dict(self.obs)
+        o["o_state"], o["o_kvalid"] = self.o_state, self.o_kvalid
+        return o
+
+    @staticmethod
+    def _shift(h, new_items):
+        """history list update: h[k] = hop k.  new_items are the most recent embeddings, newest first."""
+        d, n = h.shape[0], len(new_items)
+        for k in range(d - 1, n - 1, -1):
+            h[k].copy_(h[k - n])
+        for k in range(min(n, d)):
+            h[k].copy_(new_items[k])
+
+    def policy_step(self, forced_actions=None):
+        ag, d = self.agent, self.d
+        if d:
+            if self.hist_c is None:      # (.., a_{t-1}, c_{t-1}): hop 0 = c_{t-1}, hop 1 = a_{t-1}, hop k = old hop k-2
+                self._shift(self.hist, [self.c_cur, self.a_cur])
+                hops_a = hops_c = [self.hist[k] for k in range(d)]
+            else:
+                self._shift(self.hist, [self.a_cur])
+                self._shift(self.hist_c, [self.c_cur])
+                hops_a, hops_c = [self.hist[k] for k in range(d)], [self.hist_c[k] for k in range(d)]
+        else:
+            hops_a = hops_c = []
+        o = self._obs()
+        prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0)
+        v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True)
+        if forced_actions is not None:
+            a_n = forced_actions.to(torch.int32)
+            logp = torch.distributions.Categorical(probs=prob).log_prob(forced_actions)
+        else:
+            a_n, logp = ops.categorical_sample(prob, ag.sample_seed, 0, counter=self.counter)
+        self.ha.copy_(ha); self.hc.copy_(hc)
+        self.a_cur.copy_(a_emb); self.c_cur.copy_(c_emb)
+        self.a_n.copy_(a_n); self.logp.copy_(logp); self.v.copy_(v.reshape(self.N, self.P))
+
+    def value_step(self):
+        ag, d = self.agent, self.d
+        hops = []
+        if d:
+            h = self.hist if self.hist_c is None else self.hist_c
+            self._shift(h, [self.c_cur])
+            hops = [h[k] for k in range(d)]
+        v, hc, c_emb = ag.critic(self._obs(), hops, self.hc, 0, rollout=True)
+        self.v.copy_(v.reshape(self.N, self.P))
+
+    def replay_policy_step(self):
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+
+    def _capture(self):
+        """Records policy_step once.  The warm-up runs mutate the rollout state, so it is saved and restored."""
+        keep = [t.clone() for t in (self.ha, self.hc, self.hist, self.a_cur, self.c_cur, self.counter, self.a_n, self.logp, self.v)]
+        keep_c = self.hist_c.clone() if self.hist_c is not None else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.policy_step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.policy_step()
+        for t, k in zip((self.ha, self.hc, self.hist, self.a_cur, self.c_cur, self.counter, self.a_n, self.logp, self.v), keep):
+            t.copy_(k)
+        if keep_c is not None:
+            self.hist_c.copy_(keep_c)
+        self.graph = g

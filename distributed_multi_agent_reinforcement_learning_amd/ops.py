@@ -12,6 +12,7 @@ from . import build as _build
 
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
+           "categorical_sample_counter",
            "gru_gates_fwd", "gru_gates_bwd", "gru_seq_fwd", "gru_seq_bwd",
            "mappo_ops_error_string")
 
@@ -37,6 +38,7 @@ def load_library():
         L.dhgn_msg_agg_bwd_workspace.restype = i64
         L.gae_advnorm.argtypes = [i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
         L.categorical_sample.argtypes = [i32, i32, vp, C.c_uint64, C.c_uint64, i32, vp, vp, vp]
+        L.categorical_sample_counter.argtypes = [i32, i32, vp, C.c_uint64, vp, i32, vp, vp, vp]
         L.gru_gates_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.gru_gates_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -203,8 +205,10 @@ def gae_advnorm(r, v, active, gamma, lamda, use_adv_norm=True):
     return adv, v_target
 
 
-def categorical_sample(probs, seed, offset, greedy=False):
-    """Categorical(probs).sample() and log_prob, or argmax when greedy (reference DHGN/mappo_parallel.py:442-448)."""
+def categorical_sample(probs, seed, offset, greedy=False, counter=None):
+    """Categorical(probs).sample() and log_prob, or argmax when greedy (reference DHGN/mappo_parallel.py:442-448).
+    `counter` (int64 device tensor of one element) replaces the host-side offset: the stream position lives on the
+    device and advances by the number of rows, which makes the call replayable inside a captured graph."""
     L = load_library()
     _need_gpu(probs, "categorical_sample")
     shape = probs.shape[:-1]
@@ -213,8 +217,13 @@ def categorical_sample(probs, seed, offset, greedy=False):
     R = pr.shape[0]
     action = torch.empty(R, dtype=torch.int32, device=probs.device)
     logp = torch.empty(R, dtype=torch.float32, device=probs.device)
-    _check(L.categorical_sample(R, A, _ptr(pr), int(seed), int(offset), 1 if greedy else 0, _ptr(action), _ptr(logp), _stream()),
-           "categorical_sample")
+    if counter is not None:
+        assert counter.dtype == torch.int64 and counter.numel() == 1 and counter.is_cuda
+        _check(L.categorical_sample_counter(R, A, _ptr(pr), int(seed), _ptr(counter), 1 if greedy else 0, _ptr(action), _ptr(logp),
+                                            _stream()), "categorical_sample_counter")
+    else:
+        _check(L.categorical_sample(R, A, _ptr(pr), int(seed), int(offset), 1 if greedy else 0, _ptr(action), _ptr(logp), _stream()),
+               "categorical_sample")
     return action.reshape(shape), logp.reshape(shape)
 
 

@@ -68,6 +68,10 @@ int gae_advnorm(int32_t N, int32_t T, int32_t P, const float *r, const float *v,
  */
 int categorical_sample(int32_t R, int32_t A, const float *probs, uint64_t seed, uint64_t offset, int32_t greedy,
                        int32_t *action, float *logp, void *stream);
+/* Same with the stream offset kept in device memory (*counter, advanced by R after sampling), so the call can be
+ * captured in a hipGraph and replayed with fresh random numbers. */
+int categorical_sample_counter(int32_t R, int32_t A, const float *probs, uint64_t seed, uint64_t *counter, int32_t greedy,
+                               int32_t *action, float *logp, void *stream);
 
 /*
  * torch.nn.GRU cell between the two MFMA GEMMs (reference DHGN/mappo_parallel.py:397,424,434; gate order r, z, n):
