@@ -354,7 +354,7 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         l.parent[s_id] = (uint16_t)s_id;
         l.g[s_id] = (s_id == g_id) ? __builtin_inf() : 0.0;  // astar.py:39-40: g[goal] = inf overrides g[start]
         l.open[s_id] = 1;
-        l.olist[0] = (uint16_t)s_id;
+        l.olist[0] = (uint16_t)((sx << 8) | sy);
     }
     int cnt = 1;  // wave-uniform length of the OPEN list
     wave_sync();
@@ -364,8 +364,8 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         // --- pop: arg-min over OPEN of (f = g + 2.5 * manhattan, id); f >= 0, so its bit pattern orders like f
         unsigned int kh = ~0u, kl = ~0u, ks = ~0u;
         for (int sl = lane; sl < cnt; sl += WAVE) {
-            const int id = l.olist[sl];
-            const int x = id / SY, y = id - x * SY;
+            const int xy = l.olist[sl];  // x << 8 | y : no integer division in the scan
+            const int x = xy >> 8, y = xy & 255, id = x * SY + y;
             const double f = l.g[id] + 2.5 * (double)(abs(gx - x) + abs(gy - y));
             const unsigned long long k = (unsigned long long)__double_as_longlong(f);
             const unsigned int h = (unsigned int)(k >> 32), lo = (unsigned int)k, sel = ((unsigned int)id << 16) | (unsigned int)sl;
@@ -376,7 +376,7 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         const int bid = (int)(sel >> 16), slot = (int)(sel & 0xFFFFu);
         expanded++;
         if (bid == g_id) break;
-        const int cx = bid / SY, cy = bid - cx * SY;
+        const int cxy = l.olist[slot], cx = cxy >> 8, cy = cxy & 255;
         const double gc = l.g[bid];
         const bool cur_blocked = l.obs[bid] != 0;  // is_collision(s_start=cur, .) (astar.py:106-107)
         const int last = l.olist[cnt - 1];
@@ -385,7 +385,7 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         cnt -= 1;
         wave_sync();
         bool push = false;
-        int nid = 0;
+        int nid = 0, nxy = 0;
         if (lane < 8 && !cur_blocked) {
             // u_set order (-1,0),(-1,1),(0,1),(1,1),(1,0),(1,-1),(0,-1),(-1,-1) (astar.py:11-12); neighbours are distinct
             const int ux = (lane < 2 || lane == 7) ? -1 : ((lane >= 3 && lane <= 5) ? 1 : 0);
@@ -393,6 +393,7 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
             const int nx = cx + ux, ny = cy + uy;
             if (nx >= 0 && nx <= W && ny >= 0 && ny <= H) {  // '>' bounds: x == W and y == H are legal (astar.py:109-113)
                 nid = nx * SY + ny;
+                nxy = (nx << 8) | ny;
                 if (!l.obs[nid]) {
                     const double nc = gc + ((ux != 0 && uy != 0) ? SQRT2 : 1.0);
                     if (nc < l.g[nid]) {
@@ -405,7 +406,7 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
             }
         }
         const unsigned long long pm = __ballot(push);
-        if (push) l.olist[cnt + __popcll(pm & ((1ull << lane) - 1ull))] = (uint16_t)nid;
+        if (push) l.olist[cnt + __popcll(pm & ((1ull << lane) - 1ull))] = (uint16_t)nxy;
         cnt += __popcll(pm);
         wave_sync();
         if (it == cap - 1) *status |= PE_STATUS_ASTAR_CAP;
