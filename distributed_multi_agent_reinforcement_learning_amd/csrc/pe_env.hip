@@ -719,6 +719,12 @@ int pe_env_tick(const pe_config *cfg, const pe_state *st, const int32_t *actions
                       : launch<true, true, true, false>(cfg, st, actions, sout, oout, stream);
 }
 
+int pe_env_step_observe(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *sout, const pe_obs_out *oout,
+                        void *stream) {
+    if (!cfg || !st || !actions || !sout || !oout) return PE_ERR_NULL;
+    return launch<true, true, false, false>(cfg, st, actions, sout, oout, stream);
+}
+
 int pe_astar_batch(int32_t W, int32_t H, int32_t n, const uint8_t *obs, const int32_t *sg, int16_t *out_path, int32_t *out_len,
                    int32_t max_path, void *stream) {
     pe_config c;

@@ -57,7 +57,7 @@ class PeHostInitOut(C.Structure):
 
 
 EXPORTS = ("pe_config_check", "pe_tick_lds_bytes", "pe_env_load", "pe_env_observe", "pe_evader_step", "pe_env_step",
-           "pe_env_tick", "pe_astar_batch", "pe_error_string")
+           "pe_env_tick", "pe_env_step_observe", "pe_astar_batch", "pe_error_string")
 
 _lib = None
 
@@ -84,6 +84,7 @@ def load_library():
         L.pe_evader_step.argtypes = [vp, vp, C.c_int32, vp]
         L.pe_env_step.argtypes = [vp, vp, vp, vp, vp]
         L.pe_env_tick.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
+        L.pe_env_step_observe.argtypes = [vp, vp, vp, vp, vp, vp]
         L.pe_astar_batch.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]
         L.pe_diag_norm2.argtypes = [C.c_int32, vp, vp, vp, vp]
         L.pe_resetter_create.argtypes = [vp, vp, C.c_int32, vp]
@@ -158,26 +159,26 @@ class BatchedEnv:
         c, N, dev = pe_cfg, self.N, self.device
         WH, P = c.W * c.H, c.P
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
-        self.grid = z((N, WH), torch.uint8)
-        self.bidx = z((N, WH), torch.int16)
-        self.n_obs = z((N,), torch.int32)
-        self.defs = z((N, 4, P), torch.float64)
-        self.eva = z((N, 4), torch.float64)
-        self.target = z((N, 2), torch.int32)
-        self.tape = z((N, c.tape_len, 2), torch.int32)
-        self.meta = z((N, META_INTS), torch.int32)
-        self.path = z((N, c.max_path, 2), torch.int16)
-        self.rn = z((N, 1 + 2 * P), torch.float64)
+        self._t = dict(grid=z((N, WH), torch.uint8), bidx=z((N, WH), torch.int16), n_obs=z((N,), torch.int32),
+                       defs=z((N, 4, P), torch.float64), eva=z((N, 4), torch.float64), target=z((N, 2), torch.int32),
+                       tape=z((N, c.tape_len, 2), torch.int32), meta=z((N, META_INTS), torch.int32),
+                       path=z((N, c.max_path, 2), torch.int16), rn=z((N, 1 + 2 * P), torch.float64))
         self.o_state = z((N, c.O, 4), torch.float32)  # boundary obstacles as [x, y, 0, 0] (pursuit_env.py:22-26), padded
         self.st = PeState()
         self.st.N = N
-        for name, t in (("grid", self.grid), ("bidx", self.bidx), ("n_obs", self.n_obs), ("def_", self.defs), ("eva", self.eva),
-                        ("target", self.target), ("tape", self.tape), ("meta", self.meta), ("path", self.path), ("rn", self.rn)):
-            setattr(self.st, name, t.data_ptr())
+        for name, t in self._t.items():
+            setattr(self.st, "def_" if name == "defs" else name, t.data_ptr())
         self.t_host = None  # lockstep time_step known to the host (None: unknown -> always allow replans)
+        # replan ticks run the evader's rescan + A* on a second stream so its stragglers overlap the next policy forward
+        self.overlap_replan = True
+        self._side = torch.cuda.Stream(device=self.device)
+        self._ev_obs = torch.cuda.Event()
+        self._ev_evader = torch.cuda.Event()
+        self._pending = False
 
     # -- hand-over of Pursuit_Env.reset() results --------------------------------------------------------
     def load(self, init, reset_reward_norm=False):
+        self._join()
         """init: dict of host numpy arrays grid [N,W,H] u8, obs_xy [N,O,2] i32 (padded), n_obs [N], defenders [N,P,4] f64,
         evader [N,4] f64, target [N,2] i32, tape [N,tape_len,2] i32."""
         c, N = self.c, self.N
@@ -239,16 +240,34 @@ class BatchedEnv:
     def _may_replan(self):
         return 1 if (self.t_host is None or self.t_host % self.c.difficulty == 0) else 0
 
+    def __getattr__(self, name):
+        # state tensors (grid, bidx, n_obs, defs, eva, target, tape, meta, path, rn): reading them orders the caller's stream
+        # after an evader step that may still run on the side stream
+        t = self.__dict__.get("_t")
+        if t is not None and name in t:
+            self._join()
+            return t[name]
+        raise AttributeError(name)
+
+    def _join(self):
+        """every entry point that reads or writes environment state first waits for an evader step still in flight"""
+        if self._pending:
+            torch.cuda.current_stream().wait_event(self._ev_evader)
+            self._pending = False
+
     def observe(self, obs=None):
+        self._join()
         obs = obs if obs is not None else self.new_obs()
         o = self._obs_struct(obs)
         _check(self.L.pe_env_observe(C.byref(self.c), C.byref(self.st), C.byref(o), _stream()), "pe_env_observe")
         return obs
 
     def evader_step(self):
+        self._join()
         _check(self.L.pe_evader_step(C.byref(self.c), C.byref(self.st), self._may_replan(), _stream()), "pe_evader_step")
 
     def step(self, actions, reward=None, reward_raw=None, done=None):
+        self._join()
         a = self._actions(actions)
         if reward is None:
             reward = torch.empty((self.N, self.c.P), dtype=torch.float32, device=self.device)
@@ -263,10 +282,20 @@ class BatchedEnv:
         a = self._actions(actions)
         s = self._step_struct(reward, reward_raw, done)
         o = self._obs_struct(obs)
+        self._join()
         if self.t_host is not None:
             self.t_host += 1
-        _check(self.L.pe_env_tick(C.byref(self.c), C.byref(self.st), _ptr(a), C.byref(s), C.byref(o), self._may_replan(),
-                                  _stream()), "pe_env_tick")
+        replan = self._may_replan()
+        if replan and self.overlap_replan:
+            _check(self.L.pe_env_step_observe(C.byref(self.c), C.byref(self.st), _ptr(a), C.byref(s), C.byref(o), _stream()),
+                   "pe_env_step_observe")
+            self._ev_obs.record(torch.cuda.current_stream())
+            self._side.wait_event(self._ev_obs)
+            _check(self.L.pe_evader_step(C.byref(self.c), C.byref(self.st), 1, C.c_void_p(self._side.cuda_stream)), "pe_evader_step")
+            self._ev_evader.record(self._side)
+            self._pending = True
+            return
+        _check(self.L.pe_env_tick(C.byref(self.c), C.byref(self.st), _ptr(a), C.byref(s), C.byref(o), replan, _stream()), "pe_env_tick")
 
     def _actions(self, actions):
         if actions.dtype != torch.int32:
@@ -277,6 +306,7 @@ class BatchedEnv:
 
     # -- host read-back (tests, logging) ---------------------------------------------------------------------
     def defenders_aos(self):
+        self._join()
         return self.defs.permute(0, 2, 1).contiguous()  # [N][P][4] like get_state('defender')
 
     def status(self):

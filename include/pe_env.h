@@ -149,6 +149,12 @@ int pe_env_step(const pe_config *cfg, const pe_state *st, const int32_t *actions
 int pe_env_tick(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *sout,
                 const pe_obs_out *oout, int32_t may_replan, void *stream);
 
+/* The first two phases of the tick only (step -> observe).  Used on replan ticks so that the evader's rescan + A*
+ * (pe_evader_step on a second stream) overlaps the policy forward of the next step, which needs the observations but
+ * not the evader's new position. */
+int pe_env_step_observe(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *sout,
+                        const pe_obs_out *oout, void *stream);
+
 /* Weighted A* of the evader on one standalone problem per workgroup (astar.py:26-161); test/diagnostic entry.
  * obs: [n][(W+1)*(H+1)] device bytes, sg: [n][4] (sx,sy,gx,gy), out_path: [n][max_path][2], out_len: [n][2]
  * (true length, expansions). */
