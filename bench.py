@@ -57,6 +57,50 @@ def measure_env_tick(trainer, n_ticks):
     return sum(reg) / max(1, len(reg)), (sum(rep) / len(rep) if rep else float("nan")), sum(dur) / n_ticks
 
 
+def measure_compute_kernels(trainer, cfg):
+    """Isolated timings of the two compute-bound hand-written kernels at the update's mini-batch shape, priced against the
+    fp32 MFMA / vector peak (157.3 TFLOP/s, MI355X_MICROARCH.md) with the ALGORITHMIC flops of SURVEY 8(d)."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    dev = trainer.device
+    T, P, O, E = cfg.env.max_steps, cfg.env.num_defender, cfg.map.num_max_obstacle, cfg.algo.embedding_dim
+    mb = trainer.mini_batch_size
+
+    def timeit(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+    out = {}
+    if E == 128 and cfg.algo.rnn_hidden_dim == 128:
+        B = mb * P
+        h0 = torch.zeros(1, B, 128, device=dev)
+        gi = torch.randn(T, B, 384, device=dev)
+        o = torch.empty(T, B, 128, device=dev)
+        L = ops.load_library()
+        import ctypes as C
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        w, b = torch.randn(384, 128, device=dev) * 0.08, torch.zeros(384, device=dev)
+        t = timeit(lambda: L.gru_seq_fwd(T, B, 128, ptr(gi), ptr(w), ptr(b), ptr(h0[0]), ptr(o), None, st))
+        fl = 2.0 * T * B * 128 * 384
+        out["gru_seq_fwd"] = {"bound": "mfma", "kernel": "k_gru_seq_fwd (recurrent GEMM h W_hh^T + gates, T steps in one launch)",
+                              "achieved": round(fl / t / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4),
+                              "us_per_launch": round(t * 1e6, 1), "rows": B, "steps": T}
+    R = mb * T
+    p = torch.rand(R, P, 4, device=dev) * 40; q = torch.rand(mb, O, 4, device=dev) * 40
+    W = torch.randn(E, 4, device=dev) * 0.3; bb = torch.zeros(E, device=dev)
+    with torch.no_grad():
+        t = timeit(lambda: ops.msg_agg(p, q, None, None, W, bb, ops.ADJ_ONES, None, T))
+    fl = R * P * O * (2 * 4 * E + 3 * E)
+    out["msg_agg_fwd"] = {"bound": "mfma", "kernel": "k_msg_agg_fwd<8> (critic obstacle relation, dense)", "achieved": round(fl / t / 1e12, 2),
+                          "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4), "us_per_launch": round(t * 1e6, 1), "rows": R,
+                          "note": "algorithmic flops of the reference formulation W(p_i - q_j); the kernel evaluates c_i - d_j (fewer)"}
+    return out
+
+
 def load_pmc_traffic(N):
     """HBM bytes per launch of the regular tick from the committed rocprofv3 PMC passes (profiles/r01_tick_pmc.json,
     produced with tools/profile_tick.py; FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as read)."""
@@ -188,6 +232,7 @@ def main():
                 "traffic": load_pmc_traffic(N) if args.config in ("cfg2", "cfg3") else None,
                 "bytes_per_env_step": bytes_per_step, "us_per_launch": round(t_tick * 1e6, 2), "env_steps_per_launch": N,
                 "replan_tick_us_per_launch": round(t_replan * 1e6, 2), "episode_avg_tick_us": round(t_avg * 1e6, 2)}
+    extra = measure_compute_kernels(tr, cfg) if rank == 0 else {}
 
     out = None
     if rank == 0:
@@ -202,6 +247,7 @@ def main():
             "ppo_updates_per_s": round(args.steps * cfg.algo.epochs / dt, 4),
             "breakdown_ms": {"rollout_incl_host_reset": round(rollout_ms, 1), "gae_ppo_update_allreduce_adam": round(update_ms, 1)},
             "roofline": roofline,
+            "roofline_compute_kernels": extra,
         }
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
