@@ -247,7 +247,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
         int i = idx / P, j = idx - i * P;
         l.cond[idx] = (i <= j) && (norm2(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= c.def_comm_range);
     }
-    if (!(c.pad0 & 4)) for (int idx = lane; idx < P * O; idx += WAVE) l.oadj[idx] = 0.f;
+    for (int idx = lane; idx < P * O; idx += WAVE) l.oadj[idx] = 0.f;
     wave_sync();
     if (o.p_adj) {
         for (int idx = lane; idx < P * P; idx += WAVE) {
@@ -281,7 +281,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
     }
     // LiDAR from the truncated cell of every defender (pursuit_env.py:29-53, :201): beams x ranges out of LDS
     if (o.o_adj) {
-        const int tasks = (c.pad0 & 1) ? 0 : P * c.num_beams;
+        const int tasks = P * c.num_beams;
         for (int task = lane; task < tasks; task += WAVE) {
             int i = task / c.num_beams, b = task - i * c.num_beams;
             int cx = (int)l.def[i], cy = (int)l.def[P + i];
@@ -298,7 +298,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
             }
         }
         wave_sync();
-        if (!(c.pad0 & 2)) copy_out_f32(o.o_adj + (int64_t)env * o.o_adj_stride, l.oadj, P * O, lane);
+        copy_out_f32(o.o_adj + (int64_t)env * o.o_adj_stride, l.oadj, P * O, lane);
     }
     wave_sync();
 }
@@ -564,8 +564,8 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
     Lds l;
     lds_layout(c, OBS, EVA && REPLAN, smem, &l);
     const int WH = c.W * c.H, P = c.P;
-    if (!(c.pad0 & 8)) copy_in(l.grid, st.grid + (size_t)env * WH, WH, lane);
-    if (OBS && !(c.pad0 & 8)) copy_in(l.bidx, st.bidx + (size_t)env * WH, WH * 2, lane);
+    copy_in(l.grid, st.grid + (size_t)env * WH, WH, lane);
+    if (OBS) copy_in(l.bidx, st.bidx + (size_t)env * WH, WH * 2, lane);
     double *def_hbm = st.def + (size_t)env * 4 * P;
     double *eva_hbm = st.eva + (size_t)env * 4;
     if (lane < 4 * P) l.def[lane] = def_hbm[lane];
