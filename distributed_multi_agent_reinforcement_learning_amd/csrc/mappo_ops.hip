@@ -465,8 +465,9 @@ constexpr int GRU_LD3 = 100;  // 96 k-groups + 4 pad
 __device__ __forceinline__ int gru_gidx(int row, int k) { return ((k & 3) * GRU_RB + row) * GRU_LD3 + (k >> 2); }
 
 __global__ __launch_bounds__(512) void k_gru_seq_bwd(int T, int B, const float *dout, const float *save, const float *out, const float *h0,
-                                                     const float *w_hh, float *dgi, float *dgh, float *dh0) {
+                                                     const float *w_hh, float *dgi, float *dgh, float *dh0, float *bias_partials) {
     __shared__ __attribute__((aligned(16))) float gs[4 * GRU_RB * GRU_LD3];
+    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;  // column sums of dgi / dgh over this workgroup's rows and all steps
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int b0 = blockIdx.x * GRU_RB;
     const int c16 = l & 15, q = l >> 4;
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(512) void k_gru_seq_bwd(int T, int B, const float *
                 const size_t g = ((size_t)t * B + b0 + row) * 3 * GRU_H;
                 dgi[g + j] = dr; dgi[g + GRU_H + j] = dz; dgi[g + 2 * GRU_H + j] = dn;
                 dgh[g + j] = dr; dgh[g + GRU_H + j] = dz; dgh[g + 2 * GRU_H + j] = dnr;
+                sb_r += dr; sb_z += dz; sb_n += dn; sb_nr += dnr;
             }
             gs[gru_gidx(row, j)] = dr; gs[gru_gidx(row, GRU_H + j)] = dz; gs[gru_gidx(row, 2 * GRU_H + j)] = dnr;
         }
@@ -521,6 +523,29 @@ __global__ __launch_bounds__(512) void k_gru_seq_bwd(int T, int B, const float *
     for (int reg = 0; reg < 4; reg++) {
         const int row = 4 * q + reg;
         if (b0 + row < B) dh0[(size_t)(b0 + row) * GRU_H + j] = dcarry[reg];
+    }
+    // bias gradients: db_ih = sum (dr, dz, dn), db_hh = sum (dr, dz, dn r): per-workgroup partials, reduced by a second pass
+    sb_r += __shfl_xor(sb_r, 16); sb_z += __shfl_xor(sb_z, 16); sb_n += __shfl_xor(sb_n, 16); sb_nr += __shfl_xor(sb_nr, 16);
+    sb_r += __shfl_xor(sb_r, 32); sb_z += __shfl_xor(sb_z, 32); sb_n += __shfl_xor(sb_n, 32); sb_nr += __shfl_xor(sb_nr, 32);
+    if (q == 0 && bias_partials) {
+        float *bp = bias_partials + (size_t)blockIdx.x * 4 * GRU_H;
+        bp[j] = sb_r; bp[GRU_H + j] = sb_z; bp[2 * GRU_H + j] = sb_n; bp[3 * GRU_H + j] = sb_nr;
+    }
+}
+
+__global__ void k_gru_bias_reduce(int nblk, const float *partials, float *db_ih, float *db_hh) {
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // 4 * H columns, one wave each
+    const int lane = threadIdx.x & 63;
+    if (idx >= 4 * GRU_H) return;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += (double)partials[(size_t)b * 4 * GRU_H + idx];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        const int g = idx / GRU_H, jj = idx - g * GRU_H;
+        if (g == 0) { db_ih[jj] = (float)s; db_hh[jj] = (float)s; }
+        else if (g == 1) { db_ih[GRU_H + jj] = (float)s; db_hh[GRU_H + jj] = (float)s; }
+        else if (g == 2) db_ih[2 * GRU_H + jj] = (float)s;
+        else db_hh[2 * GRU_H + jj] = (float)s;
     }
 }
 
@@ -640,11 +665,17 @@ int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w
     return (int)hipGetLastError();
 }
 
+int64_t gru_seq_bwd_workspace(int32_t B) { return (int64_t)((B + GRU_RB - 1) / GRU_RB) * 4 * GRU_H * sizeof(float); }
+
 int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0, const float *w_hh,
-                float *dgi, float *dgh, float *dh0, void *stream) {
+                float *dgi, float *dgh, float *dh0, float *db_ih, float *db_hh, void *workspace, void *stream) {
     if (T < 1 || B < 1 || H != GRU_H || !dout || !save || !out || !h0 || !w_hh || !dgi || !dgh || !dh0) return MO_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k_gru_seq_bwd, dim3((B + GRU_RB - 1) / GRU_RB), dim3(512), 0, (hipStream_t)stream, T, B, dout, save, out, h0, w_hh, dgi,
-                       dgh, dh0);
+    if ((db_ih || db_hh) && (!db_ih || !db_hh || !workspace)) return MO_ERR_BAD_ARG;
+    const int nblk = (B + GRU_RB - 1) / GRU_RB;
+    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(nblk), dim3(512), 0, (hipStream_t)stream, T, B, dout, save, out, h0, w_hh, dgi, dgh, dh0,
+                       db_ih ? (float *)workspace : (float *)nullptr);
+    if (db_ih)
+        hipLaunchKernelGGL(k_gru_bias_reduce, dim3(4 * GRU_H / 4), dim3(256), 0, (hipStream_t)stream, nblk, (const float *)workspace, db_ih, db_hh);
     return (int)hipGetLastError();
 }
 

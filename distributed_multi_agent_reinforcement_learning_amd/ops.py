@@ -13,7 +13,7 @@ from . import build as _build
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_seq_fwd", "gru_seq_bwd",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -42,7 +42,9 @@ def load_library():
         L.gru_gates_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.gru_gates_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-        L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gru_seq_bwd_workspace.argtypes = [i32]
+        L.gru_seq_bwd_workspace.restype = i64
         L.mappo_ops_error_string.argtypes = [C.c_int]
         L.mappo_ops_error_string.restype = C.c_char_p
         _lib = L
@@ -280,9 +282,13 @@ class _GRULayer(torch.autograd.Function):
         dh_direct = torch.empty((B, H), dtype=x.dtype, device=x.device)
         dcarry = None
         st = _stream()
+        db_ih = db_hh = None
         if ctx.persistent:
-            _check(L.gru_seq_bwd(T, B, H, _ptr(dout), _ptr(save), _ptr(out), _ptr(h0), _ptr(w_hh), _ptr(dgi), _ptr(dgh), _ptr(dh_direct), st),
-                   "gru_seq_bwd")
+            db_ih = torch.empty(3 * H, dtype=x.dtype, device=x.device)
+            db_hh = torch.empty(3 * H, dtype=x.dtype, device=x.device)
+            ws = torch.empty(L.gru_seq_bwd_workspace(B), dtype=torch.uint8, device=x.device)
+            _check(L.gru_seq_bwd(T, B, H, _ptr(dout), _ptr(save), _ptr(out), _ptr(h0), _ptr(w_hh), _ptr(dgi), _ptr(dgh), _ptr(dh_direct),
+                                 _ptr(db_ih), _ptr(db_hh), _ptr(ws), st), "gru_seq_bwd")
             dcarry = dh_direct
         else:
             for t in range(T - 1, -1, -1):
@@ -296,7 +302,9 @@ class _GRULayer(torch.autograd.Function):
             dw_hh.addmm_(dgh[1:].reshape((T - 1) * B, 3 * H).t(), out[:-1].reshape((T - 1) * B, H))
         dw_ih = torch.mm(dgi2.t(), x.reshape(T * B, I))
         dx = torch.mm(dgi2, w_ih).reshape(T, B, I) if ctx.needs_input_grad[0] else None
-        return dx, dcarry, dw_ih, dw_hh, dgi2.sum(0), dgh2.sum(0)
+        if db_ih is None:
+            db_ih, db_hh = dgi2.sum(0), dgh2.sum(0)
+        return dx, dcarry, dw_ih, dw_hh, db_ih, db_hh
 
 
 def gru(x, h0, gru_module):

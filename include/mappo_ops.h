@@ -94,8 +94,11 @@ int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, 
  */
 int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
                 float *save, void *stream);
+int64_t gru_seq_bwd_workspace(int32_t B);
+/* db_ih / db_hh [3H] (optional, both or none): column sums of dgi / dgh, reduced from per-workgroup partials in
+ * `workspace` (>= gru_seq_bwd_workspace(B) bytes) by a deterministic second pass. */
 int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0,
-                const float *w_hh, float *dgi, float *dgh, float *dh0, void *stream);
+                const float *w_hh, float *dgi, float *dgh, float *dh0, float *db_ih, float *db_hh, void *workspace, void *stream);
 
 const char *mappo_ops_error_string(int code);
 
