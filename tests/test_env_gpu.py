@@ -173,3 +173,37 @@ def test_astar_cases_and_random_problems():
         assert np.array_equal(path[k, :len(ref)], ref), k
         n_long += len(ref) >= 2
     assert 20 < n_long < n
+
+
+def test_reference_default_geometry_matches_oracle():
+    """The reference's shipped configuration (15 defenders, 60x55 map; config.yaml:23,32): non-square map, P > 8 code
+    paths (16-wide register tiles), larger LDS footprint.  Device == oracle bit for bit, fused tick."""
+    P, W, H, T, N = 15, 60, 55, 25, 48
+    cfg = product_cfg(P, W, H, T, **{"map.center": [30, 25]})
+    env = _env(cfg, N)
+    init = random_init(N, P, W, H, 5, 10, seed=777)
+    env.load(init, reset_reward_norm=True)
+    ocfg, oenvs = oracle_envs_from_init(init, P, W, H, T)
+    rng = np.random.default_rng(9)
+    obs = env.new_obs()
+    reward = torch.zeros((N, P), dtype=torch.float32, device="cuda")
+    raw = torch.zeros((N, P), dtype=torch.float32, device="cuda")
+    env.observe(obs); env.evader_step()
+    for t in range(T):
+        o_dev = {k: v.cpu().numpy() for k, v in obs.items()}
+        eva = env.eva.cpu().numpy(); meta = env.meta.cpu().numpy()
+        acts = rng.integers(0, 9, (N, P)).astype(np.int32)
+        for n, oe in enumerate(oenvs):
+            ps, es, pa, ea, oa = oe.observe()
+            oe.evader_step()
+            assert np.array_equal(o_dev["p_state"][n], ps) and np.array_equal(o_dev["p_adj"][n], pa), (t, n)
+            assert np.array_equal(o_dev["e_adj"][n], ea) and np.array_equal(o_dev["o_adj"][n], oa), (t, n)
+            assert np.array_equal(eva[n], oe.state()["evader"]), (t, n)
+            assert meta[n, 1] == oe.state()["path_len"], (t, n)
+        env.tick(torch.as_tensor(acts).cuda(), obs, reward, raw)
+        r_raw = raw.cpu().numpy(); defs = env.defenders_aos().cpu().numpy()
+        for n, oe in enumerate(oenvs):
+            r, ok, _ = oe.step(acts[n])
+            oe.reward_norm(r)
+            assert np.array_equal(r_raw[n], r.astype(np.float32)) and np.array_equal(defs[n], oe.state()["defenders"]), (t, n)
+    assert not env.status().any().item()

@@ -163,3 +163,26 @@ def test_graph_replay_rollout_equals_eager_rollout():
     for k in bufs[0]:
         assert torch.equal(bufs[0][k], bufs[1][k]), k
     assert bufs[0]["a_n"].unique().numel() > 3
+
+
+@pytest.mark.parametrize("depth,P,W,H", [(0, 8, 40, 40), (1, 15, 60, 55)])
+def test_rollout_and_update_run_on_other_shapes(depth, P, W, H):
+    """depth-0 ablation ("GRU" of BASELINE config 2; the reference's own rollout crashes at depth 0) and the
+    reference's shipped 15-defender 60x55 geometry: rollout + update + optimiser step are finite and move the weights."""
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import MAPPO
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from tests.helpers import product_cfg
+    cfg = product_cfg(P, W, H, T=12, depth=depth, **({"map.center": [30, 25]} if W == 60 else {}))
+    torch.manual_seed(1)
+    agent = MAPPO(cfg, 10, 4, "Learner")
+    env = Pursuit_Env(cfg, num_envs=10)
+    before = agent.actor.GRU.weight_hh_l0.detach().clone()
+    exp_r, rb, steps = agent.explore_env(env, 1)
+    assert steps == 10 * 12 and torch.isfinite(rb.buffer["v_n"]).all() and torch.isfinite(rb.buffer["a_logprob_n"]).all()
+    with torch.enable_grad():
+        objC, objA, ag, cg = agent.train(rb, steps)
+    assert np.isfinite(objC) and np.isfinite(objA)
+    assert all(np.isfinite(g).all() for g in ag + cg if g is not None)
+    agent.ac_optimizer.step()
+    assert not torch.equal(before, agent.actor.GRU.weight_hh_l0)
+    assert len([k for k in agent.actor.state_dict() if "fcra" in k.lower()]) == 4 * depth
