@@ -37,6 +37,7 @@ def measure_env_tick(trainer, n_ticks):
     env = trainer.env
     N, P, D = env.num_envs, env.num_defender, env.pe_cfg.difficulty
     env.reset()
+    overlap, env.sim.overlap_replan = env.sim.overlap_replan, False  # per-kernel durations: keep everything on one stream
     obs = env.sim.new_obs()
     reward = torch.zeros((N, P), dtype=torch.float32, device=trainer.device)
     acts = torch.randint(0, 9, (n_ticks, N, P), dtype=torch.int32, device=trainer.device)
@@ -51,6 +52,7 @@ def measure_env_tick(trainer, n_ticks):
         kinds.append(env.sim.t_host % D == 0)
         ev[t + 1].record()
     torch.cuda.synchronize()
+    env.sim.overlap_replan = overlap
     dur = [ev[t].elapsed_time(ev[t + 1]) * 1e-3 for t in range(n_ticks)]
     reg = [d for d, k in zip(dur, kinds) if not k]
     rep = [d for d, k in zip(dur, kinds) if k]

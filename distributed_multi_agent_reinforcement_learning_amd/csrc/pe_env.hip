@@ -238,7 +238,7 @@ __device__ void dev_step(const pe_config &c, const Lds &l, int lane, const int32
 }
 
 // ---- observations: get_state, communicate, sensor (base_env.py:198-209, pursuit_env.py:182-209) --------
-__device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env, const pe_obs_out &o, int n_obs) {
+__device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env, const pe_obs_out &o, int n_obs, uint32_t *lcache) {
     const int P = c.P, O = c.O;
     if (o.p_state && lane < 4 * P) o.p_state[(int64_t)env * o.p_state_stride + lane] = (float)l.def[(lane & 3) * P + (lane >> 2)];
     if (o.e_state && lane < 4) o.e_state[(int64_t)env * o.e_state_stride + lane] = (float)l.eva[lane];
@@ -279,11 +279,31 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
         }
         o.e_adj[(int64_t)env * o.e_adj_stride + lane] = seen;
     }
-    // LiDAR from the truncated cell of every defender (pursuit_env.py:29-53, :201): beams x ranges out of LDS
+    // LiDAR from the truncated cell of every defender (pursuit_env.py:29-53, :201): beams x ranges out of LDS.
+    // The row depends on the cell only (the reference tabulates it per cell at reset), and a defender needs >= 5 ticks to
+    // leave a cell, so each defender keeps (cell, hit bits) in its record: an unchanged cell expands the cached bits, only
+    // the defenders that changed cell walk their 36 beams.  The kernel is instruction-bound, this removes ~80 % of the
+    // LiDAR instructions; results are identical by construction.
     if (o.o_adj) {
-        const int tasks = P * c.num_beams;
+        const int OW = (O + 31) >> 5, CW = 1 + OW;  // words per defender in the cache
+        uint32_t mycell = 0u;
+        bool changed = false;
+        if (lane < P) {
+            mycell = ((uint32_t)(int)l.def[lane] << 16) | (uint32_t)(int)l.def[P + lane];
+            changed = lcache[lane * CW] != mycell;
+        }
+        const unsigned long long chg = __ballot(changed);
+        for (int i = 0; i < P; i++) {  // wave-uniform
+            if ((chg >> i) & 1ull) continue;
+            for (int j = lane; j < O; j += WAVE) l.oadj[i * O + j] = (float)((lcache[i * CW + 1 + (j >> 5)] >> (j & 31)) & 1u);
+        }
+        const int n_chg = __popcll(chg);
+        const int tasks = n_chg * c.num_beams;
         for (int task = lane; task < tasks; task += WAVE) {
-            int i = task / c.num_beams, b = task - i * c.num_beams;
+            const int a = task / c.num_beams, b = task - a * c.num_beams;
+            unsigned long long m = chg;  // index of the a-th defender that changed cell
+            for (int k = 0; k < a; k++) m &= m - 1ull;
+            const int i = __ffsll((long long)m) - 1;
             int cx = (int)l.def[i], cy = (int)l.def[P + i];
             double bx = c.beam_dir[b][0], by = c.beam_dir[b][1];
             for (int r = 0; r < c.lidar_radius; r++) {
@@ -297,6 +317,19 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
                 }
             }
         }
+        wave_sync();
+        for (int i = 0; i < P; i++) {  // refresh the cache of the defenders that moved to another cell
+            if (!((chg >> i) & 1ull)) continue;
+            for (int w0 = 0; w0 < OW; w0 += 2) {
+                const int j = (w0 << 5) + lane;
+                const unsigned long long bits = __ballot(j < O && l.oadj[i * O + j] != 0.f);
+                if (lane == 0) {
+                    lcache[i * CW + 1 + w0] = (uint32_t)bits;
+                    if (w0 + 1 < OW) lcache[i * CW + 2 + w0] = (uint32_t)(bits >> 32);
+                }
+            }
+        }
+        if (changed) lcache[lane * CW] = mycell;
         wave_sync();
         copy_out_f32(o.o_adj + (int64_t)env * o.o_adj_stride, l.oadj, P * O, lane);
     }
@@ -574,7 +607,7 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
     if (lane == 0) l.misc[0] = meta[PE_META_T];
     wave_sync();
     if (STEP) dev_step(c, l, lane, actions + (size_t)env * P, meta, st.rn + (size_t)env * (1 + 2 * P), def_hbm, sout, env);
-    if (OBS) dev_observe(c, l, lane, env, oout, st.n_obs[env]);
+    if (OBS) dev_observe(c, l, lane, env, oout, st.n_obs[env], st.lcache + (size_t)env * c.P * (1 + (c.O + 31) / 32));
     if (EVA)
         dev_evader<REPLAN>(c, l, lane, meta, st.path + (size_t)env * c.max_path * 2, st.target + (size_t)env * 2,
                            st.tape + (size_t)env * c.tape_len * 2, eva_hbm);
@@ -593,6 +626,7 @@ __global__ void k_build_bidx(const pe_config c, const pe_state st, const int32_t
         if (x >= 0 && x < c.W && y >= 0 && y < c.H) b[x * c.H + y] = (int16_t)k;
     }
     if (threadIdx.x < PE_META_INTS) st.meta[(size_t)env * PE_META_INTS + threadIdx.x] = 0;
+    if (threadIdx.x < c.P) st.lcache[((size_t)env * c.P + threadIdx.x) * (1 + (c.O + 31) / 32)] = 0xFFFFFFFFu;  // empty LiDAR cache
 }
 
 // [N][P][4] (get_state order) -> [N][4][P] records

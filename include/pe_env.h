@@ -68,6 +68,8 @@ typedef struct pe_state {
     int32_t *meta;      /* [N][PE_META_INTS]                                                                     */
     int16_t *path;      /* [N][max_path][2]  tail of the A* path; path[cnt-1] is the next waypoint               */
     double *rn;         /* [N][1+2P]     reward normaliser: n, mean[P], S[P] (DHGN/normalization.py:4-22)        */
+    uint32_t *lcache;   /* [N][P][1+ceil(O/32)] per-defender LiDAR cache: cell (x<<16|y, ~0 = empty) + O hit bits: the LiDAR row
+                           only depends on the defender's cell (pursuit_env.py:201), which changes every ~5 ticks          */
 } pe_state;
 
 /* Observations, fp32, reference layouts (DHGN/mappo_parallel.py:767-771, replay_buffer.py:28-33).  Every tensor

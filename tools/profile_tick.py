@@ -20,6 +20,7 @@ ap.add_argument("--episodes", type=int, default=1)
 args = ap.parse_args()
 cfg = baseline_config(args.config, **{"runtime.num_envs": args.num_envs})
 env = Pursuit_Env(cfg, num_envs=args.num_envs)
+env.sim.overlap_replan = False  # one stream: per-kernel durations
 N, P, T = env.num_envs, env.num_defender, env.max_steps
 obs = env.sim.new_obs()
 reward = torch.zeros((N, P), dtype=torch.float32, device="cuda")
