@@ -346,7 +346,8 @@ class HostResetter:
         self.h = self.L.pe_resetter_create(C.byref(pe_cfg), C.byref(prm), self.N, _np(s))
         if not self.h:
             raise RuntimeError("pe_resetter_create failed (bad configuration)")
-        self.n_threads = int(n_threads or min(16, os.cpu_count() or 1))
+        world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+        self.n_threads = int(n_threads or max(1, min(16, (os.cpu_count() or 1) // world)))
         self.first = True
 
     def __del__(self):

@@ -4,7 +4,7 @@ Mirrors environment/pursuit_evasion_game/pursuit_env.py:56-229 (+ base_env.py) o
 independent environments at once: every method keeps the reference's name and meaning, tensors carry a leading
 environment dimension N (one reference `Worker` each).  The simulation runs in csrc/pe_env.hip through the C ABI of
 include/pe_env.h; the episode reset runs in csrc/pe_reset.cpp with per-environment replicas of the reference's RNG
-streams (environment n of rank r is seeded `seed + 1000 * r + n`).
+streams (environment n of rank r is seeded `seed + max(1000, num_envs) * r + n`).
 """
 import math
 from types import SimpleNamespace
@@ -31,7 +31,7 @@ class Pursuit_Env:
         self.pe_cfg = pe_env.make_pe_config(cfg, tape_len=int(rt.get("tape_len", 16)), max_path=int(rt.get("max_path", 128)))
         self.sim = pe_env.BatchedEnv(self.pe_cfg, self.num_envs, self.device)
         if seeds is None:
-            base = int(rt.get("seed", 0)) + 1000 * int(rank)
+            base = int(rt.get("seed", 0)) + max(1000, self.num_envs) * int(rank)  # disjoint streams per rank (1000 * rank below 1000 envs)
             seeds = [base + n for n in range(self.num_envs)]
         self.seeds = list(seeds)
         self.resetter = pe_env.HostResetter(self.pe_cfg, cfg, self.seeds)
@@ -47,11 +47,38 @@ class Pursuit_Env:
         self.time_step = 0
         self.n_episode += 1
         if init is None:
-            consumed = None if self.resetter.first else self.sim.meta[:, pe_env.META_TAPE_POS].cpu().numpy()
-            init = self.resetter.reset(consumed)
+            init = self._take_prefetched()
+            if init is None:
+                consumed = None if self.resetter.first else self.sim.meta[:, pe_env.META_TAPE_POS].cpu().numpy()
+                init = self.resetter.reset(consumed)
         self.sim.load(init)
         self.last_init = init
         return None
+
+    # ---- host reset of the NEXT episode overlapped with device work (e.g. the PPO update) ------------------------
+    def prefetch_reset(self):
+        """Starts the host-side reset of the next episode in a background thread (the C++ resetter releases the GIL).  Call
+        it once the running episode is over: the number of tape targets it consumed is read here."""
+        import threading
+        if getattr(self, "_prefetch", None) is not None:
+            return
+        consumed = None if self.resetter.first else self.sim.meta[:, pe_env.META_TAPE_POS].cpu().numpy()
+        box = {}
+
+        def work():
+            box["init"] = self.resetter.reset(consumed)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        self._prefetch = (th, box)
+
+    def _take_prefetched(self):
+        pf = getattr(self, "_prefetch", None)
+        if pf is None:
+            return None
+        th, box = pf
+        th.join()
+        self._prefetch = None
+        return box.get("init")
 
     @property
     def collision(self):

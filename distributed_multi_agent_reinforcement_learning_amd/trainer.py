@@ -30,6 +30,7 @@ def enable_tuned_gemms(path=TUNED_GEMM_FILE):
         import torch.cuda.tunable as tunable
         tunable.enable(True)
         tunable.tuning_enable(False)
+        tunable.write_file_on_exit(False)  # read-only use: ranks must not rewrite the committed table
         tunable.set_filename(path, insert_device_ordinal=False)
         return bool(tunable.read_file(path))
     except Exception:
@@ -138,6 +139,7 @@ class Trainer:
         ev[0].record()
         exp_r, buffer, steps = agent.explore_env(self.env, int(cfg.algo.sample_epi_num))
         ev[1].record()
+        self.env.prefetch_reset()  # the host builds the next episode's maps while the GPU runs the update
         self.total_steps += steps * self.world
         for _ in range(int(cfg.algo.epochs)):
             with torch.enable_grad():

@@ -82,3 +82,25 @@ def test_two_rank_bench_rehearsal(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert abs(j["value"] - 2 * 16 * 12 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+
+
+def test_prefetched_reset_equals_inline_reset(tmp_path):
+    """Overlapping the host reset of the next episode with the update does not change the episode sequence."""
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    cfg = small_cfg(tmp_path)
+    acts = torch.randint(0, 9, (6, 8, 4), dtype=torch.int32, device="cuda")
+    grids = []
+    for prefetch in (False, True):
+        env = Pursuit_Env(cfg, num_envs=8, seeds=list(range(40, 48)))
+        seq = []
+        for ep in range(3):
+            env.reset()
+            obs = env.observe(); env.attacker_step()
+            for t in range(6):
+                env.tick(acts[t], obs, torch.zeros(8, 4, device="cuda"))
+            if prefetch:
+                env.prefetch_reset()
+            seq.append((env.sim.grid.clone(), env.sim.eva.clone(), env.sim.target.clone()))
+        grids.append(seq)
+    for a, b in zip(*grids):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
