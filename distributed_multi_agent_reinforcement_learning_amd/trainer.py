@@ -30,9 +30,11 @@ def enable_tuned_gemms(path=TUNED_GEMM_FILE):
         import torch.cuda.tunable as tunable
         tunable.enable(True)
         tunable.tuning_enable(False)
-        tunable.write_file_on_exit(False)  # read-only use: ranks must not rewrite the committed table
-        tunable.set_filename(path, insert_device_ordinal=False)
-        return bool(tunable.read_file(path))
+        ok = bool(tunable.read_file(path))
+        # TunableOp rewrites its results file at interpreter exit: point it away from the committed table (one per process)
+        import tempfile
+        tunable.set_filename(os.path.join(tempfile.gettempdir(), f"dmarl_tunableop_{os.getpid()}.csv"), insert_device_ordinal=False)
+        return ok
     except Exception:
         return False
 
