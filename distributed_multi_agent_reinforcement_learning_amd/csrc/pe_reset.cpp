@@ -253,6 +253,29 @@ void *pe_resetter_create(const pe_config *cfg, const pe_reset_params *prm, int32
 
 void pe_resetter_destroy(void *h) { delete (Resetter *)h; }
 
+// Resume support: the generator streams (and the inflated maps the running episode's target re-draws use) as one blob.
+int64_t pe_resetter_state_bytes(void *h) {
+    if (!h) return 0;
+    Resetter &R = *(Resetter *)h;
+    return (int64_t)(sizeof(EnvRng) * R.rng.size() + R.inflated.size());
+}
+
+int pe_resetter_get_state(void *h, void *out) {
+    if (!h || !out) return PE_ERR_NULL;
+    Resetter &R = *(Resetter *)h;
+    memcpy(out, R.rng.data(), sizeof(EnvRng) * R.rng.size());
+    memcpy((char *)out + sizeof(EnvRng) * R.rng.size(), R.inflated.data(), R.inflated.size());
+    return 0;
+}
+
+int pe_resetter_set_state(void *h, const void *in) {
+    if (!h || !in) return PE_ERR_NULL;
+    Resetter &R = *(Resetter *)h;
+    memcpy(R.rng.data(), in, sizeof(EnvRng) * R.rng.size());
+    memcpy(R.inflated.data(), (const char *)in + sizeof(EnvRng) * R.rng.size(), R.inflated.size());
+    return 0;
+}
+
 int pe_resetter_reset(void *h, const int32_t *consumed_targets, const pe_host_init_out *out, int32_t n_threads) {
     if (!h || !out) return PE_ERR_NULL;
     Resetter &R = *(Resetter *)h;

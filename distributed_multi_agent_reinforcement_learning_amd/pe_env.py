@@ -91,6 +91,10 @@ def load_library():
         L.pe_resetter_create.restype = vp
         L.pe_resetter_destroy.argtypes = [vp]
         L.pe_resetter_reset.argtypes = [vp, vp, vp, C.c_int32]
+        L.pe_resetter_state_bytes.argtypes = [vp]
+        L.pe_resetter_state_bytes.restype = C.c_int64
+        L.pe_resetter_get_state.argtypes = [vp, vp]
+        L.pe_resetter_set_state.argtypes = [vp, vp]
         L.pe_error_string.argtypes = [C.c_int]
         L.pe_error_string.restype = C.c_char_p
         _lib = L
@@ -356,6 +360,18 @@ class HostResetter:
                 self.L.pe_resetter_destroy(self.h)
         except Exception:
             pass
+
+    def get_state(self):
+        buf = np.empty(self.L.pe_resetter_state_bytes(self.h), np.uint8)
+        _check(self.L.pe_resetter_get_state(self.h, _np(buf)), "pe_resetter_get_state")
+        return dict(blob=buf, first=self.first)
+
+    def set_state(self, state):
+        buf = np.ascontiguousarray(state["blob"], np.uint8)
+        if buf.size != self.L.pe_resetter_state_bytes(self.h):
+            raise ValueError("resetter state does not match this configuration / number of environments")
+        _check(self.L.pe_resetter_set_state(self.h, _np(buf)), "pe_resetter_set_state")
+        self.first = bool(state["first"])
 
     def reset(self, consumed_targets=None):
         c, N = self.c, self.N

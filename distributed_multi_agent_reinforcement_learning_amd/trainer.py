@@ -112,6 +112,13 @@ def save_checkpoint(actor, critic, cwd, suffix=""):
     torch.save({"actor": actor.state_dict(), "critic": critic.state_dict()}, f"{cwd}/state_dicts{suffix}.pt")
 
 
+class _Done:
+    """stand-in for an already finished prefetch thread"""
+
+    def join(self):
+        return None
+
+
 class Trainer:
     """One rank of the data-parallel job."""
 
@@ -156,6 +163,35 @@ class Trainer:
         self.iteration += 1
         self.last_events = ev  # (rollout incl. host reset, update) timings: read after a synchronize
         return steps * self.world, exp_r
+
+    # ---- resume bundle (the reference only saves weights: no optimiser state, step counter or RNG state) ----
+    def save_resume(self, path):
+        env, agent = self.env, self.agent
+        init = env._take_prefetched()  # the next episode may already be drawn: it belongs to the snapshot
+        st = getattr(agent, "_rstate", None)
+        bundle = dict(actor=agent.actor.state_dict(), critic=agent.critic.state_dict(), optimizer=agent.ac_optimizer.state_dict(),
+                      total_steps=self.total_steps, iteration=self.iteration, reward_norm=env.sim.rn.cpu(),
+                      tape_pos=env.sim.meta[:, 2].cpu(), sample_counter=None if st is None else st.counter.cpu(),
+                      resetter=env.resetter.get_state(), next_init=init, num_envs=self.num_envs, world=self.world, rank=self.rank)
+        torch.save(bundle, path)
+        if init is not None:
+            env._prefetch = (_Done(), {"init": init})
+
+    def load_resume(self, path):
+        b = torch.load(path, map_location=self.device, weights_only=False)  # our own file (numpy blobs inside)
+        if b["num_envs"] != self.num_envs or b["world"] != self.world:
+            raise ValueError("resume bundle was written for another num_envs / world size")
+        env, agent = self.env, self.agent
+        agent.actor.load_state_dict(b["actor"]); agent.critic.load_state_dict(b["critic"])
+        agent.ac_optimizer.load_state_dict(b["optimizer"])
+        self.total_steps, self.iteration = b["total_steps"], b["iteration"]
+        agent.lr_decay(self.total_steps)
+        env.sim.rn.copy_(b["reward_norm"])
+        env.sim.meta[:, 2] = b["tape_pos"].to(self.device)
+        env.resetter.set_state(b["resetter"])
+        if b["sample_counter"] is not None:
+            agent._rollout_state(env).counter.copy_(b["sample_counter"])
+        env._prefetch = (_Done(), {"init": b["next_init"]}) if b["next_init"] is not None else None
 
     def last_breakdown_ms(self):
         ev = self.last_events

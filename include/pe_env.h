@@ -126,6 +126,10 @@ typedef struct pe_host_init_out {
 void *pe_resetter_create(const pe_config *cfg, const pe_reset_params *prm, int32_t N, const uint64_t *seeds);
 void pe_resetter_destroy(void *resetter);
 int pe_resetter_reset(void *resetter, const int32_t *consumed_targets, const pe_host_init_out *out, int32_t n_threads);
+/* Opaque snapshot of every environment's generator streams (for a resume bundle; the reference cannot resume at all). */
+int64_t pe_resetter_state_bytes(void *resetter);
+int pe_resetter_get_state(void *resetter, void *out);
+int pe_resetter_set_state(void *resetter, const void *in);
 
 /* Validates a configuration against the kernels' limits. */
 int pe_config_check(const pe_config *cfg);

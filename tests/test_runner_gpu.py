@@ -104,3 +104,24 @@ def test_prefetched_reset_equals_inline_reset(tmp_path):
         grids.append(seq)
     for a, b in zip(*grids):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_resume_bundle_continues_the_run(tmp_path):
+    """weights + Adam moments + step counter + reward-normaliser + every RNG stream: a resumed run continues like the original."""
+    from distributed_multi_agent_reinforcement_learning_amd.trainer import Trainer
+    cfg = small_cfg(tmp_path)
+    a = Trainer(cfg)
+    a.iterate(); a.iterate()
+    a.save_resume(str(tmp_path / "resume.pt"))
+    a.iterate()
+    b = Trainer(cfg)
+    b.load_resume(str(tmp_path / "resume.pt"))
+    assert b.total_steps == 2 * 8 * 10 and b.iteration == 2
+    b.iterate()
+    assert b.total_steps == a.total_steps
+    assert torch.equal(a.env.sim.grid, b.env.sim.grid) and torch.equal(a.env.sim.target, b.env.sim.target)   # same maps drawn
+    assert torch.equal(a.env.sim.rn[:, 0], b.env.sim.rn[:, 0])
+    for (k, p), (_, q) in zip(a.agent.actor.state_dict().items(), b.agent.actor.state_dict().items()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), k
+    lr_a, lr_b = a.agent.ac_optimizer.param_groups[0]["lr"], b.agent.ac_optimizer.param_groups[0]["lr"]
+    assert lr_a == lr_b
