@@ -62,6 +62,7 @@ class Pursuit_Env:
         import threading
         if getattr(self, "_prefetch", None) is not None:
             return
+        self.check_status()
         consumed = None if self.resetter.first else self.sim.meta[:, pe_env.META_TAPE_POS].cpu().numpy()
         box = {}
 
@@ -70,6 +71,14 @@ class Pursuit_Env:
         th = threading.Thread(target=work, daemon=True)
         th.start()
         self._prefetch = (th, box)
+
+    def check_status(self):
+        """Raises when a kernel flagged a condition that breaks parity with the reference (include/pe_env.h PE_STATUS_*)."""
+        bits = int(self.sim.meta[:, pe_env.META_STATUS].max().item()) if self.num_envs else 0
+        if bits:
+            names = [n for b, n in ((1, "target tape exhausted (raise runtime.tape_len)"), (2, "A* iteration cap reached"),
+                                    (4, "stored path tail underflow (raise runtime.max_path)")) if bits & b]
+            raise RuntimeError("environment kernel status: " + "; ".join(names))
 
     def _take_prefetched(self):
         pf = getattr(self, "_prefetch", None)

@@ -1,0 +1,129 @@
+"""BASELINE-size checks (4096 environments, P=8, 40x40, T=150) through size-independent properties: reset invariants
+(SURVEY Q16), determinism, structural properties of the observations, sampled oracle spot checks, GAE linearity."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big_env():
+    from distributed_multi_agent_reinforcement_learning_amd.config import baseline_config
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    cfg = baseline_config("cfg3")
+    env = Pursuit_Env(cfg, num_envs=4096)
+    env.reset()
+    return cfg, env
+
+
+def test_reset_invariants_at_full_size(big_env):
+    cfg, env = big_env
+    init = env.last_init
+    N = 4096
+    grid = init["grid"].reshape(N, 40, 40)
+    assert (grid.reshape(N, -1).sum(1) <= 5 * 36).all() and (grid.reshape(N, -1).sum(1) > 0).any()
+    d = init["defenders"]
+    diff = d[:, :, None, :2] - d[:, None, :, :2]
+    dist = np.sqrt((diff ** 2).sum(-1)) + np.eye(8)[None] * 1e9
+    assert (dist.min((1, 2)) >= 4.0).all()                                   # defenders pairwise >= min_dist
+    for k in range(1, 8):                                                     # each later defender within comm range of 1-2 earlier ones
+        conn = (dist[:, k, :k] < 16).sum(1)
+        assert ((conn >= 1) & (conn <= 2)).all()
+    assert (d[..., 2:] == 0).all() and (d[..., 0] >= 0).all() and (d[..., 0] <= 39).all()
+    cells = np.rint(d[..., :2]).astype(int)
+    infl = np.zeros((N, 44, 44), bool)                                        # static map inflated by 2 (padded by 2)
+    g = np.pad(grid.astype(bool), ((0, 0), (2, 2), (2, 2)))
+    for dx in range(-2, 3):
+        for dy in range(-2, 3):
+            infl |= np.roll(np.roll(g, dx, 1), dy, 2)
+    n_idx = np.arange(N)
+    tg = init["target"]
+    assert not infl[n_idx, tg[:, 0] + 2, tg[:, 1] + 2].any()                  # target on a free cell of the inflated map
+    e = init["evader"]
+    ec = np.rint(e[:, :2]).astype(int)
+    assert not infl[n_idx, ec[:, 0] + 2, ec[:, 1] + 2].any()
+    near = np.sqrt(((cells - e[:, None, :2]) ** 2).sum(-1)).min(1)
+    assert (near < 8.0).all()                                                 # evader perceived by some defender cell
+    assert (init["n_obs"] <= 176).all() and (init["n_obs"] > 0).mean() > 0.99
+
+
+def test_observation_structure_and_determinism_at_full_size(big_env):
+    cfg, env = big_env
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    obs = {k: v.clone() for k, v in env.observe().items()}
+    again = env.observe()
+    for k in obs:
+        assert torch.equal(obs[k], again[k]), k                               # observe is idempotent
+    pa = obs["p_adj"]
+    assert (pa[:, :, 1] == 1).all()                                           # column-1 quirk (Q2)
+    assert (torch.tril(pa, -1)[:, :, [0] + list(range(2, 8))] == 0).all()     # lower triangle empty except column 1
+    assert (torch.diagonal(pa, dim1=1, dim2=2) == 1).all()
+    oa = obs["o_adj"]
+    assert set(oa.unique().tolist()) <= {0.0, 1.0} and (oa.sum(-1) <= 36).all()   # one hit per beam at most
+    pad = torch.arange(176, device="cuda")[None, None, :] >= env.n_obs[:, None, None]
+    assert (oa[pad.expand_as(oa)] == 0).all()                                 # padded obstacle slots stay zero
+    other = Pursuit_Env(cfg, num_envs=4096)                                   # same seeds -> same episode
+    other.reset()
+    o2 = other.observe()
+    for k in obs:
+        assert torch.equal(obs[k], o2[k]), k
+    a = torch.randint(0, 9, (4096, 8), dtype=torch.int32, device="cuda")
+    for e in (env, other):
+        e.attacker_step()
+        for _ in range(12):
+            e.tick(a, e.observe(), torch.zeros(4096, 8, device="cuda"))
+    assert torch.equal(env.sim.defs, other.sim.defs) and torch.equal(env.sim.eva, other.sim.eva) and torch.equal(env.sim.meta[:, :7], other.sim.meta[:, :7])  # [7] is a cycle-count diagnostic
+    assert not env.sim.status().any()
+
+
+def test_sampled_environments_match_oracle_at_full_size():
+    """64 of the 4096 environments replayed in the CPU oracle for 30 ticks: bit-identical state."""
+    from distributed_multi_agent_reinforcement_learning_amd.config import baseline_config
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from oracle import pe_oracle
+    cfg = baseline_config("cfg3")
+    env = Pursuit_Env(cfg, num_envs=4096, seeds=list(range(7000, 7000 + 4096)))
+    env.reset()
+    init = env.last_init
+    pick = np.linspace(0, 4095, 64).astype(int)
+    ocfg = pe_oracle.make_config(W=40, H=40, P=8, O=176, max_steps=150, tape_len=16)
+    oes = []
+    for n in pick:
+        oe = pe_oracle.OracleEnv(ocfg)
+        k = int(init["n_obs"][n])
+        oe.load(init["grid"][n], init["obs_xy"][n, :k], init["defenders"][n], init["evader"][n], init["target"][n], init["tape"][n])
+        oes.append(oe)
+    obs = env.observe(); env.attacker_step()
+    for oe in oes:
+        oe.observe(); oe.evader_step()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rew = torch.zeros(4096, 8, device="cuda")
+    for t in range(30):
+        a = torch.randint(0, 9, (4096, 8), dtype=torch.int32, device="cuda", generator=g)
+        env.tick(a, obs, rew)
+        an = a.cpu().numpy()
+        for n, oe in zip(pick, oes):
+            oe.step(an[n]); oe.observe(); oe.evader_step()
+    defs, eva = env.sim.defenders_aos().cpu().numpy(), env.sim.eva.cpu().numpy()
+    oadj = obs["o_adj"].cpu().numpy()
+    for n, oe in zip(pick, oes):
+        st = oe.state()
+        assert np.array_equal(defs[n], st["defenders"]) and np.array_equal(eva[n], st["evader"]), n
+        assert np.array_equal(oadj[n], oe.observe()[4]), n
+
+
+def test_gae_is_linear_in_rewards_at_full_size():
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    N, T, P = 4096, 150, 8
+    g = torch.Generator(device="cuda").manual_seed(1)
+    r1, r2 = torch.randn(N, T, P, device="cuda", generator=g), torch.randn(N, T, P, device="cuda", generator=g)
+    v = torch.zeros(N, T + 1, P, device="cuda")
+    act = torch.ones(N, T, P, device="cuda")
+    a1, _ = ops.gae_advnorm(r1, v, act, 0.99, 0.95, False)
+    a2, _ = ops.gae_advnorm(r2, v, act, 0.99, 0.95, False)
+    a12, vt = ops.gae_advnorm(r1 + 2 * r2, v, act, 0.99, 0.95, False)
+    assert torch.allclose(a12, a1 + 2 * a2, rtol=1e-4, atol=1e-4)
+    assert torch.equal(vt, a12)                                               # v == 0: target equals the advantage
+    an, _ = ops.gae_advnorm(r1, v, act, 0.99, 0.95, True)
+    assert abs(float(an.mean())) < 1e-4 and abs(float(an.std()) - 1.0) < 1e-3
