@@ -21,6 +21,8 @@
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int PE_TAPE_LDS = 32;   // tape entries kept in LDS (longer tapes fall back to a global read)
+constexpr int PE_WP_WINDOW = 16;  // waypoints kept next to the meta record (>= pops between two replans)
 constexpr double SQRT2 = 0x1.6a09e667f3bcdp+0;  // math.hypot(1, 1)  (astar.py:96)
 
 __device__ __forceinline__ int py_round(double v) { return (int)__builtin_rint(v); }
@@ -58,7 +60,7 @@ struct Lds {
     double *def;     // [4][P]
     double *prop;    // [4][P]
     double *eva;     // [4]
-    float *oadj;     // [P*O]
+    uint8_t *oadj;   // [P*O]  LiDAR hit flags as bytes (4x less LDS than floats: 16 workgroups fit a CU, one round of waves)
     uint8_t *cond;   // [P*P]
     int32_t *misc;   // [8 + 2*PE_MAX_P]: t, path_len, path_cnt, ..., rounded defender cells
     // replan scratch
@@ -67,7 +69,14 @@ struct Lds {
     uint16_t *parent;  // [(W+1)*(H+1)]
     uint16_t *olist; // [(W+1)*(H+1)]  compact OPEN list (unordered)
     double *g;       // [(W+1)*(H+1)]
-    unsigned long long *red;  // [2]  wave arg-min scratch
+    // copies of the small per-environment records, prefetched with the grids in ONE batch of global loads at kernel start
+    int32_t *m;      // [PE_META_INTS] meta | [PE_MAX_P] actions | [2] target | [2*PE_TAPE_LDS] tape | [PE_WP_WINDOW] waypoints
+    __device__ __forceinline__ int32_t *acts() const { return m + PE_META_INTS; }
+    __device__ __forceinline__ int32_t *tg() const { return m + PE_META_INTS + PE_MAX_P; }
+    __device__ __forceinline__ int32_t *tp() const { return m + PE_META_INTS + PE_MAX_P + 2; }
+    __device__ __forceinline__ uint32_t *wp() const { return (uint32_t *)(m + PE_META_INTS + PE_MAX_P + 2 + 2 * PE_TAPE_LDS); }
+    uint32_t *lc;    // [P * (1 + ceil(O/32))]  LiDAR cache
+    double *rnl;     // [1 + 2P]  reward normaliser
 };
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -77,15 +86,17 @@ __host__ __device__ inline size_t lds_layout(const pe_config &c, bool with_obs, 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
     size_t o_g = take(sizeof(double) * (with_replan ? NN : 0));
-    size_t o_red = take(sizeof(unsigned long long) * 2);
+    size_t o_rnl = take(sizeof(double) * (1 + 2 * PE_MAX_P));
     size_t o_def = take(sizeof(double) * 4 * P);
     size_t o_prop = take(sizeof(double) * 4 * P);
     size_t o_eva = take(sizeof(double) * 4);
-    size_t o_oadj = take(sizeof(float) * (with_obs ? P * c.O : 0));
+    size_t o_oadj = take(with_obs ? P * c.O : 0);
     size_t o_misc = take(sizeof(int32_t) * (8 + 2 * PE_MAX_P));
     size_t o_bidx = take(sizeof(int16_t) * (with_obs ? WH : 0));
     size_t o_parent = take(sizeof(uint16_t) * (with_replan ? NN : 0));
     size_t o_olist = take(sizeof(uint16_t) * (with_replan ? NN : 0));
+    size_t o_m = take(sizeof(int32_t) * (PE_META_INTS + PE_MAX_P + 2 + 2 * PE_TAPE_LDS + PE_WP_WINDOW));
+    size_t o_lc = take(sizeof(uint32_t) * (with_obs ? P * (1 + (c.O + 31) / 32) : 0));
     size_t o_grid = take(WH);
     size_t o_cond = take(P * P);
     size_t o_obs = take(with_replan ? NN : 0);
@@ -95,12 +106,14 @@ __host__ __device__ inline size_t lds_layout(const pe_config &c, bool with_obs, 
         l->def = (double *)(base + o_def);
         l->prop = (double *)(base + o_prop);
         l->eva = (double *)(base + o_eva);
-        l->oadj = (float *)(base + o_oadj);
+        l->oadj = base + o_oadj;
         l->misc = (int32_t *)(base + o_misc);
         l->bidx = (int16_t *)(base + o_bidx);
         l->parent = (uint16_t *)(base + o_parent);
         l->olist = (uint16_t *)(base + o_olist);
-        l->red = (unsigned long long *)(base + o_red);
+        l->rnl = (double *)(base + o_rnl);
+        l->m = (int32_t *)(base + o_m);
+        l->lc = (uint32_t *)(base + o_lc);
         l->grid = base + o_grid;
         l->cond = base + o_cond;
         l->obs = base + o_obs;
@@ -157,11 +170,12 @@ __device__ __forceinline__ void dynamic(double tau, double h, double x, double y
 __device__ __forceinline__ bool in_bound_i(const pe_config &c, int x, int y) { return x < c.W && x >= 0 && y < c.H && y >= 0; }
 
 // ---- defenders: Pursuit_Env.step + defender_reward + collision_detection (pursuit_env.py:104-177) ------
-__device__ void dev_step(const pe_config &c, const Lds &l, int lane, const int32_t *actions, int32_t *meta, double *rn,
-                         double *def_hbm, const pe_step_out &out, int env) {
+__device__ void dev_step(const pe_config &c, const Lds &l, int lane, double *def_hbm, const pe_step_out &out, int env) {
     const int P = c.P;
+    int32_t *meta = l.m;
+    double *rn = l.rnl;
     if (lane < P) {
-        int a = actions[lane];
+        int a = l.acts()[lane];
         a = a < 0 ? 0 : (a > 8 ? 8 : a);
         double o[4];
         dynamic(c.def_tau, c.def_dt, l.def[lane], l.def[P + lane], l.def[2 * P + lane], l.def[3 * P + lane], c.action_u[a][0],
@@ -230,7 +244,6 @@ __device__ void dev_step(const pe_config &c, const Lds &l, int lane, const int32
         if (c.use_reward_norm) rn[0] = rn[0] + 1.0;
         int t = meta[PE_META_T] + 1;
         meta[PE_META_T] = t;
-        l.misc[0] = t;
         if (any_coll) meta[PE_META_COLLISION] = 1;
         if (out.done) out.done[env] = (uint8_t)(t >= c.max_steps);
     }
@@ -238,7 +251,8 @@ __device__ void dev_step(const pe_config &c, const Lds &l, int lane, const int32
 }
 
 // ---- observations: get_state, communicate, sensor (base_env.py:198-209, pursuit_env.py:182-209) --------
-__device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env, const pe_obs_out &o, int n_obs, uint32_t *lcache) {
+__device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env, const pe_obs_out &o, int n_obs, uint32_t *lcache_hbm) {
+    uint32_t *lcache = l.lc;
     const int P = c.P, O = c.O;
     if (o.p_state && lane < 4 * P) o.p_state[(int64_t)env * o.p_state_stride + lane] = (float)l.def[(lane & 3) * P + (lane >> 2)];
     if (o.e_state && lane < 4) o.e_state[(int64_t)env * o.e_state_stride + lane] = (float)l.eva[lane];
@@ -247,7 +261,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
         int i = idx / P, j = idx - i * P;
         l.cond[idx] = (i <= j) && (norm2(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= c.def_comm_range);
     }
-    for (int idx = lane; idx < P * O; idx += WAVE) l.oadj[idx] = 0.f;
+    for (int idx = lane; idx < (P * O) >> 2; idx += WAVE) ((uint32_t *)l.oadj)[idx] = 0u;  // O is a multiple of 4
     wave_sync();
     if (o.p_adj) {
         for (int idx = lane; idx < P * P; idx += WAVE) {
@@ -295,7 +309,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
         const unsigned long long chg = __ballot(changed);
         for (int i = 0; i < P; i++) {  // wave-uniform
             if ((chg >> i) & 1ull) continue;
-            for (int j = lane; j < O; j += WAVE) l.oadj[i * O + j] = (float)((lcache[i * CW + 1 + (j >> 5)] >> (j & 31)) & 1u);
+            for (int j = lane; j < O; j += WAVE) l.oadj[i * O + j] = (uint8_t)((lcache[i * CW + 1 + (j >> 5)] >> (j & 31)) & 1u);
         }
         const int n_chg = __popcll(chg);
         const int tasks = n_chg * c.num_beams;
@@ -312,7 +326,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
                 if (px < 0 || px >= (double)c.W || py < 0 || py >= (double)c.H) break;
                 int id = l.bidx[(int)px * c.H + (int)py];
                 if (id >= 0) {
-                    if (id < O && id < n_obs) l.oadj[i * O + id] = 1.f;
+                    if (id < O && id < n_obs) l.oadj[i * O + id] = 1;
                     break;
                 }
             }
@@ -322,16 +336,27 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
             if (!((chg >> i) & 1ull)) continue;
             for (int w0 = 0; w0 < OW; w0 += 2) {
                 const int j = (w0 << 5) + lane;
-                const unsigned long long bits = __ballot(j < O && l.oadj[i * O + j] != 0.f);
+                const unsigned long long bits = __ballot(j < O && l.oadj[i * O + j] != 0);
                 if (lane == 0) {
-                    lcache[i * CW + 1 + w0] = (uint32_t)bits;
-                    if (w0 + 1 < OW) lcache[i * CW + 2 + w0] = (uint32_t)(bits >> 32);
+                    lcache_hbm[i * CW + 1 + w0] = (uint32_t)bits;
+                    if (w0 + 1 < OW) lcache_hbm[i * CW + 2 + w0] = (uint32_t)(bits >> 32);
                 }
             }
         }
-        if (changed) lcache[lane * CW] = mycell;
+        if (changed) lcache_hbm[lane * CW] = mycell;
         wave_sync();
-        copy_out_f32(o.o_adj + (int64_t)env * o.o_adj_stride, l.oadj, P * O, lane);
+        {   // bytes -> fp32 rows of o_adj, 16 B per lane per store
+            float *dst = o.o_adj + (int64_t)env * o.o_adj_stride;
+            const uint32_t *src = (const uint32_t *)l.oadj;
+            if ((((uintptr_t)dst) & 15) == 0) {
+                for (int i = lane; i < (P * O) >> 2; i += WAVE) {
+                    const uint32_t v = src[i];
+                    ((float4 *)dst)[i] = make_float4((float)(v & 0xFFu), (float)((v >> 8) & 0xFFu), (float)((v >> 16) & 0xFFu), (float)(v >> 24));
+                }
+            } else {
+                for (int i = lane; i < P * O; i += WAVE) dst[i] = (float)l.oadj[i];
+            }
+        }
     }
     wave_sync();
 }
@@ -472,13 +497,14 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
 }
 
 // ---- Evader.replan + rescan (agent.py:202-259, Occupied_Grid_Map.py:119-191) ----------------------------
-__device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int32_t *meta, int16_t *path, const int32_t *target) {
+__device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int16_t *path, uint32_t *wp_hbm) {
+    int32_t *meta = l.m;
+    const int32_t *target = l.tg();
     const int W = c.W, H = c.H, P = c.P, SY = H + 1, NN = (W + 1) * SY;
     const int sx = py_round(l.eva[0]), sy = py_round(l.eva[1]);
     const int gx = target[0], gy = target[1];
     int ext = c.extend_dis;
     int len = 1, cnt = 1, total_exp = 0, status = 0;
-    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     if (lane < P) { l.misc[8 + 2 * lane] = py_round(l.def[lane]); l.misc[8 + 2 * lane + 1] = py_round(l.def[P + lane]); }
     wave_sync();
     while (ext >= 0) {
@@ -520,39 +546,51 @@ __device__ void dev_replan(const pe_config &c, const Lds &l, int lane, int32_t *
         meta[PE_META_PATH_CNT] = cnt;
         meta[PE_META_ASTAR_EXP] = total_exp;
         if (status) meta[PE_META_STATUS] |= status;
-        meta[PE_META_PAD] = (int32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);  // diagnostic: shader cycles / 16 of this replan
-        l.misc[1] = len;
-        l.misc[2] = cnt;
+        meta[PE_META_WP_HEAD] = 0;
+        // the next PE_WP_WINDOW waypoints, in the order the evader visits them (path[cnt-1], path[cnt-2], ...)
+        for (int k = 0; k < PE_WP_WINDOW; k++) {
+            const int idx = cnt - 1 - k >= 0 ? cnt - 1 - k : 0;
+            const uint32_t v = ((uint32_t)(uint16_t)path[2 * idx] << 16) | (uint32_t)(uint16_t)path[2 * idx + 1];
+            l.wp()[k] = v;
+            wp_hbm[k] = v;
+        }
     }
     wave_sync();
 }
 
+// path[n-1] (the next waypoint) packed x << 16 | y: from the prefetched window, or from HBM beyond it
+__device__ __forceinline__ uint32_t dev_waypoint(const Lds &l, const int16_t *path, int head, int n) {
+    if (head < PE_WP_WINDOW) return l.wp()[head];
+    return ((uint32_t)(uint16_t)path[2 * (n - 1)] << 16) | (uint32_t)(uint16_t)path[2 * (n - 1) + 1];
+}
+
 // ---- Pursuit_Env.attacker_step (pursuit_env.py:75-102), waypoint2phi (agent.py:261-271) -----------------
 template <bool REPLAN>
-__device__ void dev_evader(const pe_config &c, const Lds &l, int lane, int32_t *meta, int16_t *path, int32_t *target,
-                           const int32_t *tape, double *eva_hbm) {
-    const int t = l.misc[0];
-    int len = meta[PE_META_PATH_LEN], cnt = meta[PE_META_PATH_CNT];
+__device__ void dev_evader(const pe_config &c, const Lds &l, int lane, int16_t *path, uint32_t *wp_hbm, int32_t *target_hbm,
+                           const int32_t *tape_hbm, double *eva_hbm) {
+    int32_t *meta = l.m;
+    const int t = meta[PE_META_T];
     if (REPLAN) {
         if (t % c.difficulty == 0) {  // wave-uniform
-            dev_replan(c, l, lane, meta, path, target);
-            len = l.misc[1];
-            cnt = l.misc[2];
-            __threadfence_block();
+            dev_replan(c, l, lane, path, wp_hbm);
         }
     }
     if (lane == 0) {
+        int len = meta[PE_META_PATH_LEN], cnt = meta[PE_META_PATH_CNT], head = meta[PE_META_WP_HEAD];
         const double ex = l.eva[0], ey = l.eva[1];
         int status = 0;
         if (cnt < 1) { status |= PE_STATUS_PATH_UNDERFLOW; cnt = 1; }
-        if (len >= 2) {
-            double lx = (double)path[2 * (cnt - 1)], ly = (double)path[2 * (cnt - 1) + 1];
-            if (norm2(ex - lx, ey - ly) < c.resolution) {
-                len--;
-                if (cnt > 1) cnt--; else status |= PE_STATUS_PATH_UNDERFLOW;
-            }
+        // path[cnt-1] is the next waypoint; the window holds it without a dependent global read
+        uint32_t wv = dev_waypoint(l, path, head, cnt);
+        double wx = (double)(int16_t)(wv >> 16), wy = (double)(int16_t)(wv & 0xFFFFu);
+        if (len >= 2 && norm2(ex - wx, ey - wy) < c.resolution) {
+            len--;
+            if (cnt > 1) {
+                cnt--; head++;
+                wv = dev_waypoint(l, path, head, cnt);
+                wx = (double)(int16_t)(wv >> 16); wy = (double)(int16_t)(wv & 0xFFFFu);
+            } else status |= PE_STATUS_PATH_UNDERFLOW;
         }
-        const double wx = (double)path[2 * (cnt - 1)], wy = (double)path[2 * (cnt - 1) + 1];
         // phi = sign(dy) * arccos(dx / (r + 1e-3)); u = vmax * (cos phi, sin phi).  cos(arccos(q)) == q and
         // sin(arccos(q)) == sqrt((1-q)(1+q)) are used in place of libm (same form in the CPU oracle); sign(0) == 0
         // gives phi == 0.
@@ -573,16 +611,19 @@ __device__ void dev_evader(const pe_config &c, const Lds &l, int lane, int32_t *
             eva_hbm[0] = ns[0]; eva_hbm[1] = ns[1]; eva_hbm[2] = ns[2]; eva_hbm[3] = ns[3];
         }
         // the target is re-drawn when the PROPOSED position reaches it (pursuit_env.py:98-100); draws come from the tape
-        if (norm2((double)target[0] - ns[0], (double)target[1] - ns[1]) <= c.eva_collision_radius) {
+        if (norm2((double)l.tg()[0] - ns[0], (double)l.tg()[1] - ns[1]) <= c.eva_collision_radius) {
             int pos = meta[PE_META_TAPE_POS];
             int k = pos < c.tape_len ? pos : c.tape_len - 1;
             if (pos >= c.tape_len) status |= PE_STATUS_TAPE_EXHAUSTED;
-            target[0] = tape[2 * k];
-            target[1] = tape[2 * k + 1];
+            int nx, ny;
+            if (k < PE_TAPE_LDS) { nx = l.tp()[2 * k]; ny = l.tp()[2 * k + 1]; } else { nx = tape_hbm[2 * k]; ny = tape_hbm[2 * k + 1]; }
+            l.tg()[0] = nx; l.tg()[1] = ny;
+            target_hbm[0] = nx; target_hbm[1] = ny;
             meta[PE_META_TAPE_POS] = pos + 1;
         }
         meta[PE_META_PATH_LEN] = len;
         meta[PE_META_PATH_CNT] = cnt;
+        meta[PE_META_WP_HEAD] = head;
         if (status) meta[PE_META_STATUS] |= status;
     }
     wave_sync();
@@ -597,20 +638,71 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
     Lds l;
     lds_layout(c, OBS, EVA && REPLAN, smem, &l);
     const int WH = c.W * c.H, P = c.P;
-    copy_in(l.grid, st.grid + (size_t)env * WH, WH, lane);
-    if (OBS) copy_in(l.bidx, st.bidx + (size_t)env * WH, WH * 2, lane);
+    const int CW = 1 + ((c.O + 31) >> 5);
     double *def_hbm = st.def + (size_t)env * 4 * P;
     double *eva_hbm = st.eva + (size_t)env * 4;
-    if (lane < 4 * P) l.def[lane] = def_hbm[lane];
-    if (lane < 4) l.eva[lane] = eva_hbm[lane];
-    int32_t *meta = st.meta + (size_t)env * PE_META_INTS;
-    if (lane == 0) l.misc[0] = meta[PE_META_T];
+    int32_t *meta_hbm = st.meta + (size_t)env * PE_META_INTS;
+    double *rn_hbm = st.rn + (size_t)env * (1 + 2 * P);
+    uint32_t *lc_hbm = st.lcache + (size_t)env * P * CW;
+    uint32_t *wp_hbm = st.wpw + (size_t)env * PE_WP_WINDOW;
+    int32_t *target_hbm = st.target + (size_t)env * 2;
+    const int32_t *tape_hbm = st.tape + (size_t)env * c.tape_len * 2;
+    // ---- ONE batch of global loads: every record this tick needs is requested before the first wait, so a wave pays the
+    // HBM/L2 latency once instead of once per phase (the kernel is latency-bound: ~3.8 k instructions in ~57 k cycles per wave)
+    const uint8_t *gsrc = st.grid + (size_t)env * WH;
+    const int16_t *bsrc = st.bidx + (size_t)env * WH;
+    const bool wide = (WH & 15) == 0 && WH <= 4096;
+    const int ng = WH >> 4, nb = WH >> 3;
+    const uint4 *g4 = (const uint4 *)gsrc, *b4 = (const uint4 *)bsrc;
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    // named registers (not an array: an indexed array would live in scratch memory)
+#define PE_LDG(k) uint4 rg##k = z4; if (wide && lane + WAVE * k < ng) rg##k = g4[lane + WAVE * k];
+#define PE_LDB(k) uint4 rb##k = z4; if (OBS && wide && lane + WAVE * k < nb) rb##k = b4[lane + WAVE * k];
+    PE_LDG(0) PE_LDG(1) PE_LDG(2) PE_LDG(3)
+    PE_LDB(0) PE_LDB(1) PE_LDB(2) PE_LDB(3) PE_LDB(4) PE_LDB(5) PE_LDB(6) PE_LDB(7)
+#undef PE_LDG
+#undef PE_LDB
+    double r_def = 0.0, r_eva = 0.0, r_rn = 0.0;
+    int32_t r_meta = 0, r_act = 0, r_tg = 0, r_tp = 0, r_nobs = 0;
+    uint32_t r_wp = 0, r_lc = 0;
+    if (lane < 4 * P) r_def = def_hbm[lane];
+    if (lane < 4) r_eva = eva_hbm[lane];
+    if (lane < PE_META_INTS) r_meta = meta_hbm[lane];
+    if (lane < 2) r_tg = target_hbm[lane];
+    if (STEP && lane < P) r_act = actions[(size_t)env * P + lane];
+    if (STEP && lane < 1 + 2 * P) r_rn = rn_hbm[lane];
+    if (OBS && lane < P * CW) r_lc = lc_hbm[lane];
+    if (OBS) r_nobs = st.n_obs[env];
+    if (EVA && lane < PE_WP_WINDOW) r_wp = wp_hbm[lane];
+    if (EVA && lane < 2 * c.tape_len && lane < 2 * PE_TAPE_LDS) r_tp = tape_hbm[lane];
+    if (wide) {
+#define PE_STG(k) if (lane + WAVE * k < ng) ((uint4 *)l.grid)[lane + WAVE * k] = rg##k;
+#define PE_STB(k) if (OBS && lane + WAVE * k < nb) ((uint4 *)l.bidx)[lane + WAVE * k] = rb##k;
+        PE_STG(0) PE_STG(1) PE_STG(2) PE_STG(3)
+        PE_STB(0) PE_STB(1) PE_STB(2) PE_STB(3) PE_STB(4) PE_STB(5) PE_STB(6) PE_STB(7)
+#undef PE_STG
+#undef PE_STB
+    } else {
+        copy_in(l.grid, gsrc, WH, lane);
+        if (OBS) copy_in(l.bidx, bsrc, WH * 2, lane);
+    }
+    if (lane < 4 * P) l.def[lane] = r_def;
+    if (lane < 4) l.eva[lane] = r_eva;
+    if (lane < PE_META_INTS) l.m[lane] = r_meta;
+    if (lane < 2) l.tg()[lane] = r_tg;
+    if (STEP && lane < P) l.acts()[lane] = r_act;
+    if (STEP && lane < 1 + 2 * P) l.rnl[lane] = r_rn;
+    if (OBS && lane < P * CW) l.lc[lane] = r_lc;
+    if (OBS && P * CW > WAVE) for (int i = WAVE + lane; i < P * CW; i += WAVE) l.lc[i] = lc_hbm[i];
+    if (EVA && lane < PE_WP_WINDOW) l.wp()[lane] = r_wp;
+    if (EVA && lane < 2 * c.tape_len && lane < 2 * PE_TAPE_LDS) l.tp()[lane] = r_tp;
     wave_sync();
-    if (STEP) dev_step(c, l, lane, actions + (size_t)env * P, meta, st.rn + (size_t)env * (1 + 2 * P), def_hbm, sout, env);
-    if (OBS) dev_observe(c, l, lane, env, oout, st.n_obs[env], st.lcache + (size_t)env * c.P * (1 + (c.O + 31) / 32));
-    if (EVA)
-        dev_evader<REPLAN>(c, l, lane, meta, st.path + (size_t)env * c.max_path * 2, st.target + (size_t)env * 2,
-                           st.tape + (size_t)env * c.tape_len * 2, eva_hbm);
+    if (STEP) dev_step(c, l, lane, def_hbm, sout, env);
+    if (OBS) dev_observe(c, l, lane, env, oout, r_nobs, lc_hbm);
+    if (EVA) dev_evader<REPLAN>(c, l, lane, st.path + (size_t)env * c.max_path * 2, wp_hbm, target_hbm, tape_hbm, eva_hbm);
+    // ---- write the small records back (def / eva / target / LiDAR cache were written where they changed)
+    if ((STEP || EVA) && lane < PE_META_INTS) meta_hbm[lane] = l.m[lane];
+    if (STEP && c.use_reward_norm && lane < 1 + 2 * P) rn_hbm[lane] = l.rnl[lane];
 }
 
 // bidx from the obstacle list (pursuit_env.py:21: index == position in np.argwhere order)
@@ -626,6 +718,7 @@ __global__ void k_build_bidx(const pe_config c, const pe_state st, const int32_t
         if (x >= 0 && x < c.W && y >= 0 && y < c.H) b[x * c.H + y] = (int16_t)k;
     }
     if (threadIdx.x < PE_META_INTS) st.meta[(size_t)env * PE_META_INTS + threadIdx.x] = 0;
+    if (threadIdx.x < PE_WP_WINDOW) st.wpw[(size_t)env * PE_WP_WINDOW + threadIdx.x] = 0u;
     if (threadIdx.x < c.P) st.lcache[((size_t)env * c.P + threadIdx.x) * (1 + (c.O + 31) / 32)] = 0xFFFFFFFFu;  // empty LiDAR cache
 }
 

@@ -29,7 +29,7 @@ class PeConfig(C.Structure):
 
 class PeState(C.Structure):
     _fields_ = [("N", C.c_int32), ("pad0", C.c_int32)] + \
-               [(n, C.c_void_p) for n in ("grid", "bidx", "n_obs", "def_", "eva", "target", "tape", "meta", "path", "rn", "lcache")]
+               [(n, C.c_void_p) for n in ("grid", "bidx", "n_obs", "def_", "eva", "target", "tape", "meta", "path", "rn", "wpw", "lcache")]
 
 
 class PeObsOut(C.Structure):
@@ -166,7 +166,7 @@ class BatchedEnv:
         self._t = dict(grid=z((N, WH), torch.uint8), bidx=z((N, WH), torch.int16), n_obs=z((N,), torch.int32),
                        defs=z((N, 4, P), torch.float64), eva=z((N, 4), torch.float64), target=z((N, 2), torch.int32),
                        tape=z((N, c.tape_len, 2), torch.int32), meta=z((N, META_INTS), torch.int32),
-                       path=z((N, c.max_path, 2), torch.int16), rn=z((N, 1 + 2 * P), torch.float64),
+                       path=z((N, c.max_path, 2), torch.int16), rn=z((N, 1 + 2 * P), torch.float64), wpw=z((N, 16), torch.int32),
                        lcache=torch.full((N, P, 1 + (c.O + 31) // 32), -1, dtype=torch.int32, device=dev))
         self.o_state = z((N, c.O, 4), torch.float32)  # boundary obstacles as [x, y, 0, 0] (pursuit_env.py:22-26), padded
         self.st = PeState()

@@ -28,7 +28,7 @@ extern "C" {
 
 /* meta[env][k] */
 enum { PE_META_T = 0, PE_META_PATH_LEN = 1, PE_META_TAPE_POS = 2, PE_META_COLLISION = 3, PE_META_PATH_CNT = 4,
-       PE_META_ASTAR_EXP = 5, PE_META_STATUS = 6, PE_META_PAD = 7 };
+       PE_META_ASTAR_EXP = 5, PE_META_STATUS = 6, PE_META_WP_HEAD = 7 /* waypoints popped since the last replan */ };
 /* meta[PE_META_STATUS] bits */
 enum { PE_STATUS_TAPE_EXHAUSTED = 1, PE_STATUS_ASTAR_CAP = 2, PE_STATUS_PATH_UNDERFLOW = 4 };
 
@@ -68,6 +68,8 @@ typedef struct pe_state {
     int32_t *meta;      /* [N][PE_META_INTS]                                                                     */
     int16_t *path;      /* [N][max_path][2]  tail of the A* path; path[cnt-1] is the next waypoint               */
     double *rn;         /* [N][1+2P]     reward normaliser: n, mean[P], S[P] (DHGN/normalization.py:4-22)        */
+    uint32_t *wpw;      /* [N][16]       the evader's next waypoints (x<<16|y) as of the last replan: path[cnt-1], path[cnt-2], ...;
+                           lets the tick prefetch them with everything else instead of a read that depends on meta        */
     uint32_t *lcache;   /* [N][P][1+ceil(O/32)] per-defender LiDAR cache: cell (x<<16|y, ~0 = empty) + O hit bits: the LiDAR row
                            only depends on the defender's cell (pursuit_env.py:201), which changes every ~5 ticks          */
 } pe_state;
