@@ -62,7 +62,7 @@ struct Lds {
     double *eva;     // [4]
     uint8_t *oadj;   // [P*O]  LiDAR hit flags as bytes (4x less LDS than floats: 16 workgroups fit a CU, one round of waves)
     uint8_t *cond;   // [P*P]
-    int32_t *misc;   // [8 + 2*PE_MAX_P]: t, path_len, path_cnt, ..., rounded defender cells
+    int32_t *misc;   // [8 + 2*PE_MAX_P]: [8..] rounded defender cells (replan)
     // replan scratch
     uint8_t *obs;    // [(W+1)*(H+1)]
     uint8_t *open;   // [(W+1)*(H+1)]  node is in the OPEN list
@@ -320,14 +320,35 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
             const int i = __ffsll((long long)m) - 1;
             int cx = (int)l.def[i], cy = (int)l.def[P + i];
             double bx = c.beam_dir[b][0], by = c.beam_dir[b][1];
-            for (int r = 0; r < c.lidar_radius; r++) {
-                double px = (double)cx + (double)r * bx;
-                double py = (double)cy + (double)r * by;
-                if (px < 0 || px >= (double)c.W || py < 0 || py >= (double)c.H) break;
-                int id = l.bidx[(int)px * c.H + (int)py];
-                if (id >= 0) {
-                    if (id < O && id < n_obs) l.oadj[i * O + id] = 1;
-                    break;
+            if (c.lidar_radius <= 8) {
+                // all range samples of the beam are looked up at once (independent LDS reads in flight together: the kernel
+                // is latency-bound), then the first sample that leaves the map or hits a boundary cell decides
+                int ids[8];
+                bool oob[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const double px = (double)cx + (double)r * bx, py = (double)cy + (double)r * by;
+                    oob[r] = (r >= c.lidar_radius) || px < 0 || px >= (double)c.W || py < 0 || py >= (double)c.H;
+                    ids[r] = l.bidx[oob[r] ? 0 : (int)px * c.H + (int)py];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if (oob[r]) break;
+                    if (ids[r] >= 0) {
+                        if (ids[r] < O && ids[r] < n_obs) l.oadj[i * O + ids[r]] = 1;
+                        break;
+                    }
+                }
+            } else {
+                for (int r = 0; r < c.lidar_radius; r++) {
+                    double px = (double)cx + (double)r * bx;
+                    double py = (double)cy + (double)r * by;
+                    if (px < 0 || px >= (double)c.W || py < 0 || py >= (double)c.H) break;
+                    int id = l.bidx[(int)px * c.H + (int)py];
+                    if (id >= 0) {
+                        if (id < O && id < n_obs) l.oadj[i * O + id] = 1;
+                        break;
+                    }
                 }
             }
         }
