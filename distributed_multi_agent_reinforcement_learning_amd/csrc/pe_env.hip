@@ -35,7 +35,7 @@ __device__ __forceinline__ unsigned int dpp_mov(unsigned int v) {
     return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
 // Wave-wide lexicographic arg-min of (kh, kl, ks); every lane ends up with the minimum triple.  Four row-rotate DPP
-// steps reduce inside the 16-lane rows on the VALU, two ds_bpermute steps combine the four rows.  (An LDS atomic-min on
+// steps reduce inside the 16-lane rows on the VALU, v_readlane + scalar compares combine the four rows.  (An LDS atomic-min on
 // one address would be serialised lane by lane by the compiler's atomic optimiser: ~14 scalar instructions per active lane.)
 __device__ __forceinline__ void wave_argmin3(unsigned int &kh, unsigned int &kl, unsigned int &ks) {
 #define PE_TAKE(oh, ol, os)                                                                   \
@@ -48,8 +48,22 @@ __device__ __forceinline__ void wave_argmin3(unsigned int &kh, unsigned int &kl,
     PE_DPP_STEP(0x122)  // row_ror:2
     PE_DPP_STEP(0x124)  // row_ror:4
     PE_DPP_STEP(0x128)  // row_ror:8
-    { const unsigned int oh = __shfl_xor(kh, 16), ol = __shfl_xor(kl, 16), os = __shfl_xor(ks, 16); PE_TAKE(oh, ol, os) }
-    { const unsigned int oh = __shfl_xor(kh, 32), ol = __shfl_xor(kl, 32), os = __shfl_xor(ks, 32); PE_TAKE(oh, ol, os) }
+    // every lane of a 16-lane row now holds the row minimum: combine the four rows through scalar registers
+    // (v_readlane + SALU compares) instead of two more cross-lane ds_bpermute round trips
+    {
+        unsigned int bh = (unsigned int)__builtin_amdgcn_readlane((int)kh, 0), bl = (unsigned int)__builtin_amdgcn_readlane((int)kl, 0),
+                     bs = (unsigned int)__builtin_amdgcn_readlane((int)ks, 0);
+#define PE_ROW(L)                                                                                                           \
+        {                                                                                                                   \
+            const unsigned int oh = (unsigned int)__builtin_amdgcn_readlane((int)kh, L), ol = (unsigned int)__builtin_amdgcn_readlane((int)kl, L), \
+                               os = (unsigned int)__builtin_amdgcn_readlane((int)ks, L);                                    \
+            const bool t = oh < bh || (oh == bh && (ol < bl || (ol == bl && os < bs)));                                     \
+            bh = t ? oh : bh; bl = t ? ol : bl; bs = t ? os : bs;                                                           \
+        }
+        PE_ROW(16) PE_ROW(32) PE_ROW(48)
+#undef PE_ROW
+        kh = bh; kl = bl; ks = bs;
+    }
 #undef PE_DPP_STEP
 #undef PE_TAKE
 }
