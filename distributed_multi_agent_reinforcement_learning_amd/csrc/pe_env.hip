@@ -28,44 +28,59 @@ constexpr double SQRT2 = 0x1.6a09e667f3bcdp+0;  // math.hypot(1, 1)  (astar.py:9
 __device__ __forceinline__ int py_round(double v) { return (int)__builtin_rint(v); }
 __device__ __forceinline__ double norm2(double a, double b) { return __builtin_sqrt(__builtin_fma(b, b, a * a)); }
 
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }  // one wave per workgroup: LDS visibility fence
+// One wave per workgroup: the lanes only ever exchange data with lanes of their own wave.  A wave's LDS and vector-memory
+// instructions execute in program order through the same LDS / L1, so a wavefront-scope fence (no s_waitcnt, no s_barrier)
+// plus the compiler scheduling barrier is all the ordering the exchange needs; __syncthreads() would drain every
+// outstanding global load/store (vmcnt(0)) at each of the ~20 sync points of a tick.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <int CTRL>
 __device__ __forceinline__ unsigned int dpp_mov(unsigned int v) {
     return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
-// Wave-wide lexicographic arg-min of (kh, kl, ks); every lane ends up with the minimum triple.  Four row-rotate DPP
-// steps reduce inside the 16-lane rows on the VALU, v_readlane + scalar compares combine the four rows.  (An LDS atomic-min on
-// one address would be serialised lane by lane by the compiler's atomic optimiser: ~14 scalar instructions per active lane.)
-__device__ __forceinline__ void wave_argmin3(unsigned int &kh, unsigned int &kl, unsigned int &ks) {
-#define PE_TAKE(oh, ol, os)                                                                   \
-    {                                                                                         \
-        const bool t = (oh) < kh || ((oh) == kh && ((ol) < kl || ((ol) == kl && (os) < ks))); \
-        kh = t ? (oh) : kh; kl = t ? (ol) : kl; ks = t ? (os) : ks;                           \
+// Wave-wide lexicographic arg-min of (f, sel), f >= 0 (or +inf); every lane ends up with the minimum pair.  Two short
+// reductions instead of one over a 96-bit key: v_min_f64 over f, then v_min_u32 over the sel of the lanes that hold the
+// minimum f.  Four row-rotate DPP steps reduce inside the 16-lane rows on the VALU, v_readlane combines the four rows.
+// (An LDS atomic-min on one address would be serialised lane by lane by the compiler's atomic optimiser.)
+__device__ __forceinline__ void wave_argmin_f(double &f, unsigned int &sel) {
+    double m = f;
+#define PE_DPP_STEP(CTRL)                                                                                     \
+    {                                                                                                         \
+        const unsigned long long k = (unsigned long long)__double_as_longlong(m);                             \
+        const unsigned int oh = dpp_mov<CTRL>((unsigned int)(k >> 32)), ol = dpp_mov<CTRL>((unsigned int)k);  \
+        m = __builtin_fmin(m, __longlong_as_double((long long)(((unsigned long long)oh << 32) | ol)));        \
     }
-#define PE_DPP_STEP(CTRL) { const unsigned int oh = dpp_mov<CTRL>(kh), ol = dpp_mov<CTRL>(kl), os = dpp_mov<CTRL>(ks); PE_TAKE(oh, ol, os) }
     PE_DPP_STEP(0x121)  // row_ror:1
     PE_DPP_STEP(0x122)  // row_ror:2
     PE_DPP_STEP(0x124)  // row_ror:4
     PE_DPP_STEP(0x128)  // row_ror:8
-    // every lane of a 16-lane row now holds the row minimum: combine the four rows through scalar registers
-    // (v_readlane + SALU compares) instead of two more cross-lane ds_bpermute round trips
-    {
-        unsigned int bh = (unsigned int)__builtin_amdgcn_readlane((int)kh, 0), bl = (unsigned int)__builtin_amdgcn_readlane((int)kl, 0),
-                     bs = (unsigned int)__builtin_amdgcn_readlane((int)ks, 0);
-#define PE_ROW(L)                                                                                                           \
-        {                                                                                                                   \
-            const unsigned int oh = (unsigned int)__builtin_amdgcn_readlane((int)kh, L), ol = (unsigned int)__builtin_amdgcn_readlane((int)kl, L), \
-                               os = (unsigned int)__builtin_amdgcn_readlane((int)ks, L);                                    \
-            const bool t = oh < bh || (oh == bh && (ol < bl || (ol == bl && os < bs)));                                     \
-            bh = t ? oh : bh; bl = t ? ol : bl; bs = t ? os : bs;                                                           \
-        }
-        PE_ROW(16) PE_ROW(32) PE_ROW(48)
-#undef PE_ROW
-        kh = bh; kl = bl; ks = bs;
-    }
 #undef PE_DPP_STEP
-#undef PE_TAKE
+    {
+        const unsigned long long k = (unsigned long long)__double_as_longlong(m);
+        const int kh = (int)(k >> 32), kl = (int)(unsigned int)k;
+#define PE_ROWF(L) __longlong_as_double((long long)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(kh, L) << 32) | (unsigned int)__builtin_amdgcn_readlane(kl, L)))
+        m = __builtin_fmin(__builtin_fmin(PE_ROWF(0), PE_ROWF(16)), __builtin_fmin(PE_ROWF(32), PE_ROWF(48)));
+#undef PE_ROWF
+    }
+    unsigned int s = (f == m) ? sel : ~0u;
+#define PE_DPP_STEP(CTRL) { const unsigned int o = dpp_mov<CTRL>(s); s = o < s ? o : s; }
+    PE_DPP_STEP(0x121)
+    PE_DPP_STEP(0x122)
+    PE_DPP_STEP(0x124)
+    PE_DPP_STEP(0x128)
+#undef PE_DPP_STEP
+    {
+        const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)s, 0), r1 = (unsigned int)__builtin_amdgcn_readlane((int)s, 16),
+                           r2 = (unsigned int)__builtin_amdgcn_readlane((int)s, 32), r3 = (unsigned int)__builtin_amdgcn_readlane((int)s, 48);
+        const unsigned int a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+        s = a < b ? a : b;
+    }
+    f = m;
+    sel = s;
 }
 
 struct Lds {
@@ -399,8 +414,8 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
 // ---- weighted A* (astar.py:26-161) on an LDS-resident problem ------------------------------------------
 // OPEN is a compact unordered list of node ids in LDS (at most one live entry per node); the pop is a wave-wide
 // arg-min of (f, x, y) over the list, which is the order heapq yields for (f, (x, y)) tuples: lanes scan the list,
-// one ds_min_u64 on the bit pattern of f (f >= 0, so the pattern is monotone) finds the minimum, a ds_min_u32 over
-// the lanes that hold it breaks ties by node id (id order == (x, y) tuple order).  Stale duplicates of the
+// a wave-wide min over f finds the minimum, a min over the node ids of the lanes that hold it breaks ties (id order ==
+// (x, y) tuple order; wave_argmin_f).  Stale duplicates of the
 // reference's heap never change g/PARENT when popped (same g, same sums), so keeping only the live entry is
 // equivalent.  Returns the true path length (goal -> start); stores the last min(len, max_path) nodes in path_out.
 __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, int gx, int gy, int16_t *path_out, int max_path,
@@ -455,17 +470,16 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
     int expanded = 0;
     for (int it = 0; it < cap && cnt > 0; it++) {
         // --- pop: arg-min over OPEN of (f = g + 2.5 * manhattan, id); f >= 0, so its bit pattern orders like f
-        unsigned int kh = ~0u, kl = ~0u, ks = ~0u;
+        double fb = __builtin_inf();
+        unsigned int sel = ~0u;
         for (int sl = lane; sl < cnt; sl += WAVE) {
             const int xy = l.olist[sl];  // x << 8 | y : no integer division in the scan
             const int x = xy >> 8, y = xy & 255, id = x * SY + y;
             const double f = l.g[id] + 2.5 * (double)(abs(gx - x) + abs(gy - y));
-            const unsigned long long k = (unsigned long long)__double_as_longlong(f);
-            const unsigned int h = (unsigned int)(k >> 32), lo = (unsigned int)k, sel = ((unsigned int)id << 16) | (unsigned int)sl;
-            if (h < kh || (h == kh && (lo < kl || (lo == kl && sel < ks)))) { kh = h; kl = lo; ks = sel; }
+            const unsigned int se = ((unsigned int)id << 16) | (unsigned int)sl;
+            if (f < fb || (f == fb && se < sel)) { fb = f; sel = se; }
         }
-        wave_argmin3(kh, kl, ks);
-        const unsigned int sel = ks;
+        wave_argmin_f(fb, sel);
         const int bid = (int)(sel >> 16), slot = (int)(sel & 0xFFFFu);
         expanded++;
         if (bid == g_id) break;
@@ -478,23 +492,24 @@ __device__ int dev_astar(int W, int H, const Lds &l, int lane, int sx, int sy, i
         cnt -= 1;
         wave_sync();
         bool push = false;
-        int nid = 0, nxy = 0;
+        int nxy = 0;
         if (lane < 8 && !cur_blocked) {
             // u_set order (-1,0),(-1,1),(0,1),(1,1),(1,0),(1,-1),(0,-1),(-1,-1) (astar.py:11-12); neighbours are distinct
             const int ux = (lane < 2 || lane == 7) ? -1 : ((lane >= 3 && lane <= 5) ? 1 : 0);
             const int uy = (lane >= 1 && lane <= 3) ? 1 : ((lane >= 5) ? -1 : 0);
             const int nx = cx + ux, ny = cy + uy;
             if (nx >= 0 && nx <= W && ny >= 0 && ny <= H) {  // '>' bounds: x == W and y == H are legal (astar.py:109-113)
-                nid = nx * SY + ny;
+                const int nid = nx * SY + ny;
                 nxy = (nx << 8) | ny;
-                if (!l.obs[nid]) {
-                    const double nc = gc + ((ux != 0 && uy != 0) ? SQRT2 : 1.0);
-                    if (nc < l.g[nid]) {
-                        l.g[nid] = nc;
-                        l.parent[nid] = (uint16_t)bid;
-                        push = l.open[nid] == 0;
-                        l.open[nid] = 1;
-                    }
+                // the three lookups are independent: one LDS round trip instead of three nested ones
+                const uint8_t nb = l.obs[nid], nopen = l.open[nid];
+                const double gn = l.g[nid];
+                const double nc = gc + ((ux != 0 && uy != 0) ? SQRT2 : 1.0);
+                if (!nb && nc < gn) {
+                    l.g[nid] = nc;
+                    l.parent[nid] = (uint16_t)bid;
+                    l.open[nid] = 1;
+                    push = nopen == 0;
                 }
             }
         }
