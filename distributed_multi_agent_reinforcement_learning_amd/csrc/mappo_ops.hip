@@ -563,6 +563,151 @@ int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, cons
 
 constexpr int BWD_BLOCKS = 1024;
 
+// ---- weight-gradient GEMM  C[M][N] = A^T B  (A [K][M], B [K][N] row-major, K ~ 5e5 rows, M, N <= 384) -------------
+// The (rows x features) activations / output gradients of a Linear or GRU projection are reduced over every row of the
+// minibatch: a tall-skinny "TN" GEMM whose whole output fits the accumulators of ONE workgroup.  Split-K: workgroup x
+// owns a contiguous range of 4-row k-steps and the full (128 AM) x (128 BN) tile, 2 x 2 waves of (64 AM) x (64 BN) each,
+// all accumulators in registers (AM * BN * 16 tiles of v_mfma_f32_16x16x4_f32 per wave).  Both operands are K-major, which
+// is exactly the MFMA A/B lane order (lane = 16 * k + i): they go from global memory straight into the MFMA operand
+// registers with 16-byte loads and never touch LDS -- lane (i, k) loads 4 consecutive features [4i, 4i+4) of row k, and
+// feature 4i + t is declared row i of tile t (a permutation of the output rows undone when the partial is stored).
+// Loads of the next chunk of k-steps are issued before the MFMAs of the current one (register double buffer).  The
+// partial tiles go to `part` [S][M][N]; k_wgrad_reduce adds them in a fixed order (deterministic, no atomics).
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int AM, int BN, int U>
+struct WgradRegs {
+    float4 a[U][AM], b[U][BN];
+};
+
+template <int AM, int BN, int U>
+__device__ __forceinline__ void wgrad_load(WgradRegs<AM, BN, U> &r, const float *pa, const float *pb, int64_t lda4, int64_t ldb4) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int a = 0; a < AM; a++) r.a[u][a] = *(const float4 *)(pa + u * lda4 + a * 64);
+#pragma unroll
+        for (int b = 0; b < BN; b++) r.b[u][b] = *(const float4 *)(pb + u * ldb4 + b * 64);
+    }
+}
+
+template <int AM, int BN, int U>
+__device__ __forceinline__ void wgrad_mma(const WgradRegs<AM, BN, U> &r, v4f (&acc)[AM][4][BN][4]) {
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int a = 0; a < AM; a++) {
+            const float av[4] = {r.a[u][a].x, r.a[u][a].y, r.a[u][a].z, r.a[u][a].w};
+#pragma unroll
+            for (int b = 0; b < BN; b++) {
+                const float bv[4] = {r.b[u][b].x, r.b[u][b].y, r.b[u][b].z, r.b[u][b].w};
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) acc[a][t][b][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[v], acc[a][t][b][v], 0, 0, 0);
+            }
+        }
+}
+
+template <int AM, int BN>
+__global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int64_t K,
+                                               int M, int N, float *__restrict__ part) {
+    constexpr int U = 4;  // k-steps per pipeline stage (measured: 2 exposes load latency, 6+ lengthens the unpipelined ends)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 15, kk = lane >> 4;
+    const int m0 = blockIdx.y * 128 * AM + (wave >> 1) * 64 * AM, n0 = blockIdx.z * 128 * BN + (wave & 1) * 64 * BN;
+    const int64_t steps = K >> 2;  // full 4-row k-steps; rows 4*steps .. K-1 are the masked tail of the last workgroup
+    const int64_t s_beg = steps * blockIdx.x / gridDim.x, s_end = steps * (blockIdx.x + 1) / gridDim.x;
+    const int64_t lda4 = 4 * lda, ldb4 = 4 * ldb;
+    const float *pa = A + (4 * s_beg + kk) * lda + m0 + 4 * i;
+    const float *pb = B + (4 * s_beg + kk) * ldb + n0 + 4 * i;
+    v4f acc[AM][4][BN][4];
+#pragma unroll
+    for (int a = 0; a < AM; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int b = 0; b < BN; b++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) acc[a][t][b][v] = (v4f){0.f, 0.f, 0.f, 0.f};
+    // Straight-line pipeline (no branch around a load: the s_waitcnt counts stay exact): pairs of U-step chunks, the
+    // loads of the chunk after next are issued before the MFMAs of the current one; past the end the last chunk is
+    // re-loaded (discarded) instead of branching.
+    const int64_t n_s = s_end - s_beg, pairs = n_s / (2 * U);
+    WgradRegs<AM, BN, U> r0, r1;
+    if (pairs > 0) wgrad_load<AM, BN, U>(r0, pa, pb, lda4, ldb4);
+    for (int64_t c = 0; c < pairs; c++) {
+        wgrad_load<AM, BN, U>(r1, pa + U * lda4, pb + U * ldb4, lda4, ldb4);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler would sink it to its use)
+        wgrad_mma<AM, BN, U>(r0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t adv = (c + 1 < pairs) ? 2 * U : U;
+        pa += adv * lda4;
+        pb += adv * ldb4;
+        wgrad_load<AM, BN, U>(r0, pa, pb, lda4, ldb4);
+        __builtin_amdgcn_sched_barrier(0);
+        wgrad_mma<AM, BN, U>(r1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // the n_s % 2U left-over steps, then (last workgroup) the K % 4 tail rows, zero-filled
+        pa = A + (4 * (s_beg + pairs * 2 * U) + kk) * lda + m0 + 4 * i;
+        pb = B + (4 * (s_beg + pairs * 2 * U) + kk) * ldb + n0 + 4 * i;
+        WgradRegs<AM, BN, 1> r;
+        for (int64_t s = s_beg + pairs * 2 * U; s < s_end; s++) {
+            wgrad_load<AM, BN, 1>(r, pa, pb, lda4, ldb4);
+            wgrad_mma<AM, BN, 1>(r, acc);
+            pa += lda4;
+            pb += ldb4;
+        }
+        if (blockIdx.x == gridDim.x - 1 && (K & 3)) {
+            const bool live = 4 * steps + kk < K;
+#pragma unroll
+            for (int a = 0; a < AM; a++) r.a[0][a] = live ? *(const float4 *)(pa + a * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int b = 0; b < BN; b++) r.b[0][b] = live ? *(const float4 *)(pb + b * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wgrad_mma<AM, BN, 1>(r, acc);
+        }
+    }
+    // D tile (a,t | b,v): lane l, register q holds row 4 (l / 16) + q, column l % 16 of the tile, i.e. output row
+    // m0 + 64 a + 16 (l / 16) + 4 q + t and column n0 + 64 b + 4 (l % 16) + v: the four v's are one 16-byte store
+    float *po = part + ((size_t)blockIdx.x * M + m0 + 16 * kk) * N + n0 + 4 * i;
+#pragma unroll
+    for (int a = 0; a < AM; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int b = 0; b < BN; b++)
+                    *(float4 *)(po + (size_t)(64 * a + 4 * q + t) * N + 64 * b) =
+                        make_float4(acc[a][t][b][0][q], acc[a][t][b][1][q], acc[a][t][b][2][q], acc[a][t][b][3][q]);
+}
+
+// C[m][n] = (accumulate ? C[m][n] : 0) + sum_x part[x][m][n], x ascending: the same order every run
+__global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float *__restrict__ part, float *__restrict__ C, int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= MN) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int x = 0;
+    for (; x + 4 <= S; x += 4) {
+        s0 += part[(size_t)x * MN + idx];
+        s1 += part[(size_t)(x + 1) * MN + idx];
+        s2 += part[(size_t)(x + 2) * MN + idx];
+        s3 += part[(size_t)(x + 3) * MN + idx];
+    }
+    for (; x < S; x++) s0 += part[(size_t)x * MN + idx];
+    const float s = (s0 + s1) + (s2 + s3);
+    C[idx] = accumulate ? C[idx] + s : s;
+}
+
+int wgrad_split(int M, int N, int *am, int *bn) {  // tile shape and number of K-splits: one workgroup per CU
+    *am = (M == 384 && N == 128) ? 3 : 1;
+    *bn = (M == 128 && N == 384) ? 3 : 1;
+    const int tiles = (M / (128 * *am)) * (N / (128 * *bn));
+    int S = 256 / tiles;
+    return S < 1 ? 1 : S;
+}
+
 }  // namespace
 
 extern "C" {
@@ -676,6 +821,28 @@ int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float 
                        db_ih ? (float *)workspace : (float *)nullptr);
     if (db_ih)
         hipLaunchKernelGGL(k_gru_bias_reduce, dim3(4 * GRU_H / 4), dim3(256), 0, (hipStream_t)stream, nblk, (const float *)workspace, db_ih, db_hh);
+    return (int)hipGetLastError();
+}
+
+int64_t wgrad_tn_workspace(int32_t M, int32_t N) {
+    if (M < 128 || N < 128 || (M & 127) || (N & 127)) return -1;
+    int am, bn;
+    return (int64_t)wgrad_split(M, N, &am, &bn) * M * N * sizeof(float);
+}
+
+int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
+             void *workspace, void *stream) {
+    if (K < 1 || M < 128 || N < 128 || (M & 127) || (N & 127) || M > 1024 || N > 1024 || !A || !B || !C || !workspace) return MO_ERR_BAD_ARG;
+    if (lda < M || ldb < N || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return MO_ERR_BAD_ARG;
+    int am, bn;
+    const int S = wgrad_split(M, N, &am, &bn);
+    const dim3 grid(S, M / (128 * am), N / (128 * bn));
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    if (am == 3) hipLaunchKernelGGL((k_wgrad<3, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
+    else if (bn == 3) hipLaunchKernelGGL((k_wgrad<1, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
+    else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate);
     return (int)hipGetLastError();
 }
 

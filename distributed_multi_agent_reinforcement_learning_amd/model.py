@@ -69,10 +69,11 @@ class DHGN(nn.Module):
         M = self.MSG_layers
         m3 = ops.msg_agg3(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
                           is_critic, o_kvalid, q_div)                                  # (R, P, 3, E)
-        emb = F.relu(self.AGG_layers["AGG_vertex_0"](m3))                             # one GEMM for the three relations
+        agg0 = self.AGG_layers["AGG_vertex_0"]
+        emb = F.relu(ops.linear(m3, agg0.weight, agg0.bias))                          # one GEMM for the three relations
         # semantic_layer([p, emb0, emb1, emb2]) without materialising the concatenation (:284-303)
         Ws = self.semantic_layer.weight
-        h0 = F.linear(emb.reshape(R * P, 3 * E), Ws[:, ind:]) + F.linear(p.reshape(R * P, ind), Ws[:, :ind], self.semantic_layer.bias)
+        h0 = ops.linear(emb.reshape(R * P, 3 * E), Ws[:, ind:]) + F.linear(p.reshape(R * P, ind), Ws[:, :ind], self.semantic_layer.bias)
         return h0.reshape(R, P, E)
 
     # -- fixed-depth recursive aggregation over neighbours' historical embeddings (:204-233) --------------
@@ -85,9 +86,10 @@ class DHGN(nn.Module):
         adj = torch.ones_like(adj_p) if is_critic else adj_p
         abar = F.normalize(adj, p=1, dim=-1)
         for k in range(self.depth):
-            agg = F.relu(self.AGG_layers[f"AGG_fcra_{k}"](torch.matmul(abar, hist[k])))
+            aggk = self.AGG_layers[f"AGG_fcra_{k}"]
+            agg = F.relu(ops.linear(torch.matmul(abar, hist[k]), aggk.weight, aggk.bias))
             Wf = self.FCRA_layers[k].weight  # FCRA_k([agg, h]) as two accumulating GEMMs instead of a concatenation
-            h = F.relu(F.linear(agg, Wf[:, :E]) + F.linear(h, Wf[:, E:], self.FCRA_layers[k].bias))
+            h = F.relu(ops.linear(agg, Wf[:, :E]) + ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias))
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1):

@@ -7,13 +7,14 @@ import ctypes as C
 import os
 
 import torch
+import torch.nn.functional as F
 
 from . import build as _build
 
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -45,6 +46,9 @@ def load_library():
         L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_seq_bwd_workspace.argtypes = [i32]
         L.gru_seq_bwd_workspace.restype = i64
+        L.wgrad_tn_workspace.argtypes = [i32, i32]
+        L.wgrad_tn_workspace.restype = i64
+        L.wgrad_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
         L.mappo_ops_error_string.argtypes = [C.c_int]
         L.mappo_ops_error_string.restype = C.c_char_p
         _lib = L
@@ -229,6 +233,64 @@ def categorical_sample(probs, seed, offset, greedy=False, counter=None):
     return action.reshape(shape), logp.reshape(shape)
 
 
+WGRAD_MIN_ROWS = 4096  # below this the BLAS library's single-workgroup-tile GEMMs are as fast
+
+
+def _wgrad_ok(a, b):
+    return (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
+            and a.shape[0] == b.shape[0] and a.shape[0] >= WGRAD_MIN_ROWS
+            and a.shape[1] % 128 == 0 and b.shape[1] % 128 == 0 and a.shape[1] <= 1024 and b.shape[1] <= 1024
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def wgrad(a, b, out=None, accumulate=False):
+    """a^T b for a (K, M), b (K, N) row-major (rows may be strided): the weight gradient of a Linear / GRU projection over
+    the K rows of a minibatch (the `grad_output.t() @ input` of autograd, DHGN/mappo_parallel.py:660-708).  Shapes the
+    split-K MFMA kernel covers (M, N multiples of 128) run in csrc/mappo_ops.hip k_wgrad, the rest in the BLAS library."""
+    if not _wgrad_ok(a, b):
+        if out is None:
+            return torch.mm(a.t(), b)
+        return out.addmm_(a.t(), b) if accumulate else torch.mm(a.t(), b, out=out)
+    L = load_library()
+    M, N = a.shape[1], b.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+        accumulate = False
+    assert out.is_contiguous() and out.shape == (M, N)
+    ws = torch.empty(L.wgrad_tn_workspace(M, N), dtype=torch.uint8, device=a.device)
+    _check(L.wgrad_tn(a.shape[0], M, N, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(bool(accumulate)), _ptr(ws), _stream()),
+           "wgrad_tn")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """F.linear whose weight gradient runs in the split-K MFMA kernel (wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return F.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g2 = g.reshape(-1, W.shape[0])
+        x2 = x.reshape(-1, W.shape[1])
+        dx = torch.mm(g2, W).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dW = wgrad(g2, x2) if ctx.needs_input_grad[1] else None
+        db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    """F.linear(x, W, b) (W may be a column slice of a larger weight); under autograd the weight gradient uses wgrad."""
+    if torch.is_grad_enabled() and (W.requires_grad or x.requires_grad):
+        return _Linear.apply(x, W, b)
+    return F.linear(x, W, b)
+
+
 PERSISTENT_GRU_MIN_T = 2  # sequences at least this long take the one-launch recurrence (H = 128)
 
 
@@ -299,8 +361,8 @@ class _GRULayer(torch.autograd.Function):
         dgi2, dgh2 = dgi.reshape(T * B, 3 * H), dgh.reshape(T * B, 3 * H)
         dw_hh = torch.mm(dgh[0].t(), h0)
         if T > 1:
-            dw_hh.addmm_(dgh[1:].reshape((T - 1) * B, 3 * H).t(), out[:-1].reshape((T - 1) * B, H))
-        dw_ih = torch.mm(dgi2.t(), x.reshape(T * B, I))
+            wgrad(dgh[1:].reshape((T - 1) * B, 3 * H), out[:-1].reshape((T - 1) * B, H), out=dw_hh, accumulate=True)
+        dw_ih = wgrad(dgi2, x.reshape(T * B, I))
         dx = torch.mm(dgi2, w_ih).reshape(T, B, I) if ctx.needs_input_grad[0] else None
         if db_ih is None:
             db_ih, db_hh = dgi2.sum(0), dgh2.sum(0)

@@ -100,6 +100,19 @@ int64_t gru_seq_bwd_workspace(int32_t B);
 int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0,
                 const float *w_hh, float *dgi, float *dgh, float *dh0, float *db_ih, float *db_hh, void *workspace, void *stream);
 
+/*
+ * Weight gradient of a Linear / GRU projection, C = A^T B reduced over all K rows of a minibatch:
+ *   C [M][N] (dense) = (accumulate ? C : 0) + sum_k A[k][:]^T B[k][:] ;  A [K][M] (lda), B [K][N] (ldb), row-major fp32.
+ * Replaces the `grad_output.t() @ input` GEMMs autograd runs for torch.nn.Linear / torch.nn.GRU weights in
+ * MAPPO.train (DHGN/mappo_parallel.py:660-708, loss.backward()).  Split-K over one workgroup per CU, fp32 MFMA,
+ * partial tiles in `workspace` (>= wgrad_tn_workspace(M, N) bytes) added in a fixed order: results are deterministic.
+ * M, N multiples of 128 (<= 1024), lda/ldb multiples of 4, A/B 16-byte aligned; anything else -> MO_ERR_BAD_ARG
+ * (the caller keeps such shapes on the BLAS library).
+ */
+int64_t wgrad_tn_workspace(int32_t M, int32_t N);
+int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
+             void *workspace, void *stream);
+
 const char *mappo_ops_error_string(int code);
 
 #ifdef __cplusplus

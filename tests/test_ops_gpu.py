@@ -147,3 +147,54 @@ def test_fused_gru_matches_torch_gru(T, B):
     assert torch.allclose(hd.grad.cpu(), h0.grad, rtol=1e-4, atol=1e-5)
     for (k, p), (_, q) in zip(ref.named_parameters(), dev.named_parameters()):
         assert torch.allclose(q.grad.cpu(), p.grad, rtol=1e-4, atol=1e-4 * p.grad.abs().max().item()), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,M,N,pad", [(492000, 384, 128, 0), (492000, 128, 384, 4), (487203, 128, 128, 0), (4099, 256, 128, 0),
+                                       (4096, 128, 256, 8), (65537, 384, 128, 0)])
+def test_wgrad_matches_f64_reference(K, M, N, pad):
+    """split-K MFMA weight-gradient GEMM (csrc/mappo_ops.hip k_wgrad) vs a float64 a^T b; K % 4 tails, strided rows,
+    accumulate, run-to-run determinism"""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(K + M)
+    a_full = torch.randn((K, M + pad), generator=g, device="cuda")
+    b_full = torch.randn((K, N + pad), generator=g, device="cuda")
+    a, b = a_full[:, :M], b_full[:, :N]
+    ref = torch.zeros((M, N), dtype=torch.float64, device="cuda")
+    for s in range(0, K, 65536):  # chunked: bounds the f64 copies
+        ref += a[s:s + 65536].double().t() @ b[s:s + 65536].double()
+    got = ops.wgrad(a, b)
+    scale = float(K) ** 0.5
+    assert (got.double() - ref).abs().max().item() < 2e-5 * scale  # fp32 accumulation of K unit-variance products
+    again = ops.wgrad(a, b)
+    assert torch.equal(got, again)
+    base = torch.randn((M, N), generator=g, device="cuda")
+    acc = base.clone()
+    ops.wgrad(a, b, out=acc, accumulate=True)
+    assert (acc.double() - (ref + base.double())).abs().max().item() < 2e-5 * scale + 1e-5
+
+
+@pytest.mark.gpu
+def test_wgrad_unsupported_shapes_use_blas():
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    a = torch.randn((5000, 9), device="cuda")
+    b = torch.randn((5000, 128), device="cuda")
+    torch.testing.assert_close(ops.wgrad(a, b), a.t() @ b, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_linear_autograd_matches_torch():
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((8192, 3, 128), generator=g, device="cuda", requires_grad=True)
+    W = torch.randn((128, 132), generator=g, device="cuda", requires_grad=True)
+    bias = torch.randn((128,), generator=g, device="cuda", requires_grad=True)
+    gout = torch.randn((8192, 3, 128), generator=g, device="cuda")
+    y = ops.linear(x, W[:, 4:], bias)
+    y.backward(gout)
+    got = (y.detach().clone(), x.grad.clone(), W.grad.clone(), bias.grad.clone())
+    x.grad = W.grad = bias.grad = None
+    y2 = torch.nn.functional.linear(x, W[:, 4:], bias)
+    y2.backward(gout)
+    for u, v in zip(got, (y2.detach(), x.grad, W.grad, bias.grad)):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=2e-3)
