@@ -458,6 +458,115 @@ __global__ __launch_bounds__(512) void k_gru_seq_fwd(int T, int B, const float *
     }
 }
 
+// ---- one GRU step for a large batch (the rollout: B = envs x agents rows, T = 1) ---------------------------------------
+// torch.nn.GRU cell (I = H = 128) in ONE launch instead of two GEMMs plus a gate kernel: the workgroups are persistent
+// (one per CU), wave w keeps the W_ih AND W_hh rows of hidden units 16w..16w+15 (r, z, n: 192 VGPRs) as MFMA B-operands and
+// loops over 16-row tiles; the x and h tiles go through LDS in A-operand order (double buffered, the global loads of
+// the next tile are in flight during the MFMAs), r and z accumulate the input and the recurrent product in the same
+// accumulator, the gate math runs on the C layout with no exchange.
+__global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, const float *__restrict__ x, const float *__restrict__ hprev,
+                                                  const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                                  const float *__restrict__ b_ih, const float *__restrict__ b_hh, float *__restrict__ hout) {
+    constexpr int TILE = 4 * GRU_RB * GRU_LD;
+    __shared__ __attribute__((aligned(16))) float smem[8 * 16 * GRU_H];  // 64 KB: weight staging, then the x / h tiles
+    float (*xs)[TILE] = (float (*)[TILE])smem;
+    float (*hs)[TILE] = (float (*)[TILE])(smem + 2 * TILE);
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int c16 = l & 15, q = l >> 4;
+    const int j = 16 * w + c16;
+    float wir[32], wiz[32], win[32], whr[32], whz[32], whn[32];
+    {   // weights -> registers through LDS: the 16 rows of one gate a wave needs are 8 KB contiguous in memory (coalesced
+        // 16-byte loads), lane (c16, q) then picks W[row c16][4 kk + q]; columns are XOR-swizzled by the row to spread banks
+        float *wb = smem + w * 16 * GRU_H;
+#define GRU_STAGE_W(dst, W, gate)                                                                        \
+        {                                                                                                \
+            const float4 *src = (const float4 *)((W) + (size_t)((gate) * GRU_H + 16 * w) * GRU_H);         \
+            _Pragma("unroll") for (int i = 0; i < 8; i++) {                                              \
+                const int idx = l + 64 * i, row = idx >> 5, col = (idx & 31) * 4;                        \
+                *(float4 *)(wb + row * GRU_H + (col ^ ((row & 7) * 4))) = src[idx];                      \
+            }                                                                                            \
+            __syncthreads();                                                                             \
+            _Pragma("unroll") for (int kk = 0; kk < 32; kk++) dst[kk] = wb[c16 * GRU_H + ((4 * kk + q) ^ ((c16 & 7) * 4))]; \
+            __syncthreads();                                                                             \
+        }
+        GRU_STAGE_W(wir, w_ih, 0) GRU_STAGE_W(wiz, w_ih, 1) GRU_STAGE_W(win, w_ih, 2)
+        GRU_STAGE_W(whr, w_hh, 0) GRU_STAGE_W(whz, w_hh, 1) GRU_STAGE_W(whn, w_hh, 2)
+#undef GRU_STAGE_W
+    }
+    const float bir = b_ih[j], biz = b_ih[GRU_H + j], bin = b_ih[2 * GRU_H + j];
+    const float bhr = b_hh[j], bhz = b_hh[GRU_H + j], bhn = b_hh[2 * GRU_H + j];
+    // staging: thread e moves 4 consecutive k of one row (512 threads x float4 = one 16 x 128 tile)
+    const int srow = tid >> 5, sk = (tid & 31) * 4;
+    const int sidx = (0 * GRU_RB + srow) * GRU_LD + (sk >> 2);  // plane (k & 3) adds GRU_RB * GRU_LD
+    float4 px, ph;
+    int blk = blockIdx.x;
+    auto fetch = [&](int bk) {
+        const int row = bk * GRU_RB + srow;
+        if (row < B) {
+            px = *(const float4 *)(x + (size_t)row * GRU_H + sk);
+            ph = *(const float4 *)(hprev + (size_t)row * GRU_H + sk);
+        } else {
+            px = ph = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+        float *xd = &xs[buf][sidx], *hd = &hs[buf][sidx];
+        xd[0] = px.x; xd[GRU_RB * GRU_LD] = px.y; xd[2 * GRU_RB * GRU_LD] = px.z; xd[3 * GRU_RB * GRU_LD] = px.w;
+        hd[0] = ph.x; hd[GRU_RB * GRU_LD] = ph.y; hd[2 * GRU_RB * GRU_LD] = ph.z; hd[3 * GRU_RB * GRU_LD] = ph.w;
+    };
+    if (blk < nblk) { fetch(blk); stage(0); }
+    __syncthreads();
+    int cur = 0;
+    for (; blk < nblk; blk += gridDim.x) {
+        const int nxt = blk + gridDim.x;
+        if (nxt < nblk) fetch(nxt);  // in flight during the MFMAs below
+        const float *xp = &xs[cur][(q * GRU_RB + c16) * GRU_LD];
+        const float *hp = &hs[cur][(q * GRU_RB + c16) * GRU_LD];
+        // r and z first (input and recurrent product in one accumulator each), then the two n products: the sigmoids of
+        // r and z are VALU work the scheduler can run under the n-gate MFMAs
+        f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, ain = ar, ahn = ar;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; k4++) {
+            const f32x4 ax = *(const f32x4 *)(xp + 4 * k4);
+            const f32x4 ah = *(const f32x4 *)(hp + 4 * k4);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u], wir[4 * k4 + u], ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u], wiz[4 * k4 + u], az, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], whr[4 * k4 + u], ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], whz[4 * k4 + u], az, 0, 0, 0);
+            }
+        }
+        float rg[4], zg[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            rg[reg] = sigmoidf_(ar[reg] + bir + bhr);
+            zg[reg] = sigmoidf_(az[reg] + biz + bhz);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < 8; k4++) {
+            const f32x4 ax = *(const f32x4 *)(xp + 4 * k4);
+            const f32x4 ah = *(const f32x4 *)(hp + 4 * k4);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ain = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u], win[4 * k4 + u], ain, 0, 0, 0);
+                ahn = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], whn[4 * k4 + u], ahn, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = 4 * q + reg;
+            const float hpv = hs[cur][gru_hidx(row, j)];
+            const float r = rg[reg], z = zg[reg];
+            const float n = tanhf(ain[reg] + bin + r * (ahn[reg] + bhn));
+            if (blk * GRU_RB + row < B) hout[(size_t)(blk * GRU_RB + row) * GRU_H + j] = (1.f - z) * n + z * hpv;
+        }
+        if (nxt < nblk) stage(cur ^ 1);  // the other buffer: its last readers passed the barrier of the previous tile
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // backward of the sequence: dgi, dgh [T][B][3H] for the later weight-gradient GEMMs, dh0 [B][H].
 // dL/dh_{t-1} = dh_t z_t + dgh_t W_hh : the (16 x 384) dgh tile goes through LDS in A-operand order, W_hh columns
 // 16w..16w+15 are the B-operand of wave w (96 VGPRs), and the result lands in the lane that owns that (row, hidden unit).
@@ -800,6 +909,18 @@ int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, 
     const int n = B * (H >> 2);
     hipLaunchKernelGGL(k_gru_gates_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, H, dout, dcarry, save, h_prev, dgi, dgh,
                        dh_direct);
+    return (int)hipGetLastError();
+}
+
+int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,
+                 const float *b_hh, float *h_out, void *stream) {
+    if (B < 1 || H != GRU_H || !x || !h_prev || !w_ih || !w_hh || !b_ih || !b_hh || !h_out) return MO_ERR_BAD_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)h_prev & 15)) return MO_ERR_BAD_ARG;
+    const int nblk = (B + GRU_RB - 1) / GRU_RB;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int grid = nblk < cus ? nblk : cus;
+    hipLaunchKernelGGL(k_gru_cell, dim3(grid), dim3(512), 0, (hipStream_t)stream, (int)B, nblk, x, h_prev, w_ih, w_hh, b_ih, b_hh, h_out);
     return (int)hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ from . import build as _build
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -42,6 +42,7 @@ def load_library():
         L.categorical_sample_counter.argtypes = [i32, i32, vp, C.c_uint64, vp, i32, vp, vp, vp]
         L.gru_gates_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.gru_gates_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gru_cell_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_seq_bwd_workspace.argtypes = [i32]
@@ -291,6 +292,7 @@ def linear(x, W, b=None):
     return F.linear(x, W, b)
 
 
+FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel
 PERSISTENT_GRU_MIN_T = 2  # sequences at least this long take the one-launch recurrence (H = 128)
 
 
@@ -306,9 +308,9 @@ class _GRULayer(torch.autograd.Function):
         H = w_hh.shape[1]
         x = x.contiguous()
         h0 = h0.contiguous()
-        gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t()).reshape(T, B, 3 * H)
-        out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
         need = any(ctx.needs_input_grad)
+        out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
+        gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t()).reshape(T, B, 3 * H)
         save = torch.empty((T, 4, B, H), dtype=x.dtype, device=x.device) if need else None
         b_hh = b_hh.contiguous()
         st = _stream()
@@ -374,9 +376,19 @@ def gru(x, h0, gru_module):
     x (T, B, I), h0 (num_layers, B, H) -> out (T, B, H), h_n (num_layers, B, H)."""
     hn = []
     inp = x
+    T, B = x.shape[0], x.shape[1]
     for layer in range(gru_module.num_layers):
         w_ih, w_hh = getattr(gru_module, f"weight_ih_l{layer}"), getattr(gru_module, f"weight_hh_l{layer}")
         b_ih, b_hh = getattr(gru_module, f"bias_ih_l{layer}"), getattr(gru_module, f"bias_hh_l{layer}")
-        inp = _GRULayer.apply(inp, h0[layer], w_ih, w_hh, b_ih, b_hh)
+        if T == 1 and not torch.is_grad_enabled() and w_hh.shape[1] == 128 and w_ih.shape[1] == 128 and B >= FUSED_CELL_MIN_ROWS:
+            # rollout step: both projections + gates in one persistent launch (csrc/mappo_ops.hip k_gru_cell)
+            _need_gpu(inp, "gru")
+            out = torch.empty((1, B, 128), dtype=inp.dtype, device=inp.device)
+            _check(load_library().gru_cell_fwd(B, 128, _ptr(inp.contiguous()), _ptr(h0[layer].contiguous()), _ptr(w_ih.detach().contiguous()),
+                                               _ptr(w_hh.detach().contiguous()), _ptr(b_ih.detach().contiguous()),
+                                               _ptr(b_hh.detach().contiguous()), _ptr(out), _stream()), "gru_cell_fwd")
+            inp = out
+        else:
+            inp = _GRULayer.apply(inp, h0[layer], w_ih, w_hh, b_ih, b_hh)
         hn.append(inp[-1])
     return inp, torch.stack(hn, 0)

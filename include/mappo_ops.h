@@ -101,6 +101,15 @@ int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float 
                 const float *w_hh, float *dgi, float *dgh, float *dh0, float *db_ih, float *db_hh, void *workspace, void *stream);
 
 /*
+ * One torch.nn.GRU layer step for a large batch without autograd (the rollout's choose_action / get_value,
+ * DHGN/mappo_parallel.py:422-425 with seq_len 1): h_out = GRUCell(x, h_prev), both projections and the gate math in
+ * one persistent launch (weights in registers as fp32 MFMA operands).  I = H = 128; x, h_prev, h_out [B][H] dense;
+ * w_ih, w_hh [3H][H] (torch gate order r, z, n); h_out must not alias x or h_prev.
+ */
+int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,
+                 const float *b_hh, float *h_out, void *stream);
+
+/*
  * Weight gradient of a Linear / GRU projection, C = A^T B reduced over all K rows of a minibatch:
  *   C [M][N] (dense) = (accumulate ? C : 0) + sum_k A[k][:]^T B[k][:] ;  A [K][M] (lda), B [K][N] (ldb), row-major fp32.
  * Replaces the `grad_output.t() @ input` GEMMs autograd runs for torch.nn.Linear / torch.nn.GRU weights in
