@@ -6,6 +6,7 @@
 // test is wave-uniform (sparse LiDAR rows skip ~80 % of the neighbours) and p/q/adj are LDS broadcasts.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "mappo_ops.h"
 
@@ -672,6 +673,39 @@ int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, cons
 
 constexpr int BWD_BLOCKS = 1024;
 
+// ---- per-tick recording of the rollout into the replay buffer ------------------------------------------------------------
+// One launch instead of ~10 strided tensor copies: workgroup n moves environment n's row of every item from the rollout's
+// static tensors into slot [n, t] of the (N, T, ...) buffer tensors (dst rows are dst_row_stride bytes apart), converts the
+// int32 actions to the buffer's float32 on the way, and adds the tick's raw team reward to the episode return.
+struct RecordArgs {
+    mo_record_item it[MO_RECORD_MAX_ITEMS];
+    int n_items;
+    const float *raw;  // [N][P] or null
+    float *ret;        // [N]
+    int P;
+};
+
+__global__ __launch_bounds__(256) void k_rollout_record(RecordArgs a) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int k = 0; k < a.n_items; k++) {
+        const mo_record_item &it = a.it[k];
+        const char *src = (const char *)it.src + (size_t)n * it.row_bytes;
+        char *dst = (char *)it.dst + (size_t)n * it.dst_row_stride;
+        if (it.i32_to_f32) {
+            for (int i = tid; i < (it.row_bytes >> 2); i += 256) ((float *)dst)[i] = (float)((const int32_t *)src)[i];
+        } else if (((it.row_bytes | it.dst_row_stride) & 15) == 0 && ((((uintptr_t)it.src) | ((uintptr_t)it.dst)) & 15) == 0) {
+            for (int i = tid; i < (it.row_bytes >> 4); i += 256) ((float4 *)dst)[i] = ((const float4 *)src)[i];
+        } else {
+            for (int i = tid; i < (it.row_bytes >> 2); i += 256) ((float *)dst)[i] = ((const float *)src)[i];
+        }
+    }
+    if (a.raw && tid == 0) {
+        float s = 0.f;
+        for (int p = 0; p < a.P; p++) s += a.raw[(size_t)n * a.P + p];
+        a.ret[n] += s;
+    }
+}
+
 // ---- weight-gradient GEMM  C[M][N] = A^T B  (A [K][M], B [K][N] row-major, K ~ 5e5 rows, M, N <= 384) -------------
 // The (rows x features) activations / output gradients of a Linear or GRU projection are reduced over every row of the
 // minibatch: a tall-skinny "TN" GEMM whose whole output fits the accumulators of ONE workgroup.  Split-K: workgroup x
@@ -964,6 +998,24 @@ int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const
     else if (bn == 3) hipLaunchKernelGGL((k_wgrad<1, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
     else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate);
+    return (int)hipGetLastError();
+}
+
+int rollout_record(int32_t N, int32_t n_items, const mo_record_item *items, const float *raw, float *episode_return, int32_t P, void *stream) {
+    if (N < 1 || n_items < 0 || n_items > MO_RECORD_MAX_ITEMS || (n_items && !items) || (raw && (!episode_return || P < 1))) return MO_ERR_BAD_ARG;
+    RecordArgs a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < n_items; k++) {
+        if (!items[k].src || !items[k].dst || items[k].row_bytes < 4 || (items[k].row_bytes & 3) || (items[k].dst_row_stride & 3) ||
+            (((uintptr_t)items[k].src | (uintptr_t)items[k].dst) & 3))
+            return MO_ERR_BAD_ARG;
+        a.it[k] = items[k];
+    }
+    a.n_items = n_items;
+    a.raw = raw;
+    a.ret = episode_return;
+    a.P = P;
+    hipLaunchKernelGGL(k_rollout_record, dim3(N), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

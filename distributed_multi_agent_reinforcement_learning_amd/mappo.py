@@ -230,25 +230,24 @@ class MAPPO:
         env.attacker_step()
         use_graph = self.use_graphs and actions_override is None
         for t in range(T):
-            for k in obs_keys:
-                buf[k][rows, t].copy_(st.obs[k])
+            items = [(st.obs[k], buf[k][rows, t]) for k in obs_keys]   # the policy program only reads st.obs
             if actions_override is not None:
                 st.policy_step(actions_override[rows, t].to(self.device).long())
             elif use_graph:
                 st.replay_policy_step()
             else:
                 st.policy_step()
-            buf["actor_historical_embedding"][rows, t + d].copy_(st.a_cur)
-            buf["critic_historical_embedding"][rows, t + d].copy_(st.c_cur)
-            buf["v_n"][rows, t].copy_(st.v)
-            buf["a_n"][rows, t].copy_(st.a_n)          # int32 -> float32 like the reference buffer
-            buf["a_logprob_n"][rows, t].copy_(st.logp)
+            items += [(st.a_cur, buf["actor_historical_embedding"][rows, t + d]), (st.c_cur, buf["critic_historical_embedding"][rows, t + d]),
+                      (st.v, buf["v_n"][rows, t]), (st.a_n, buf["a_n"][rows, t]),      # int32 -> float32 like the reference buffer
+                      (st.logp, buf["a_logprob_n"][rows, t])]
+            # one launch records the tick (and adds the previous tick's raw reward to the episode return)
+            ops.rollout_record(items, raw if t > 0 else None, episode_reward)
             if t + 1 < T:
                 env.tick(st.a_n, st.obs, buf["r"][rows, t], raw)
             else:
                 env.sim.step(st.a_n, buf["r"][rows, t], raw)
                 env.time_step += 1
-            episode_reward += raw.sum(-1)
+        episode_reward += raw.sum(-1)
         buf["active"][rows].fill_(1.0)
         # bootstrap value of the state after the last step (:807-825): only the critic's embedding enters the history
         env.observe(st.obs)
@@ -327,14 +326,17 @@ class _RolloutState:
         else:
             hops_a = hops_c = []
         o = self._obs()
-        prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0)
-        v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True)
+        prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True)
+        v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True)
         if forced_actions is not None:
             a_n = forced_actions.to(torch.int32)
             logp = torch.distributions.Categorical(probs=prob).log_prob(forced_actions)
         else:
             a_n, logp = ops.categorical_sample(prob, ag.sample_seed, 0, counter=self.counter)
-        self.ha.copy_(ha); self.hc.copy_(hc)
+        if ha is not self.ha:
+            self.ha.copy_(ha)
+        if hc is not self.hc:
+            self.hc.copy_(hc)
         self.a_cur.copy_(a_emb); self.c_cur.copy_(c_emb)
         self.a_n.copy_(a_n); self.logp.copy_(logp); self.v.copy_(v.reshape(self.N, self.P))
 

@@ -100,9 +100,9 @@ class DHGN(nn.Module):
 class _Trunk(nn.Module):
     """shared_net -> GRU -> Mean, common to actor and critic."""
 
-    def _rollout_features(self, embedding, hidden_state):
+    def _rollout_features(self, embedding, hidden_state, inplace_hidden=False):
         R, P, E = embedding.shape
-        feat, hidden_state = ops.gru(embedding.reshape(1, R * P, E), hidden_state, self.GRU)
+        feat, hidden_state = ops.gru(embedding.reshape(1, R * P, E), hidden_state, self.GRU, inplace_hidden)
         return feat.reshape(R, P, self.rnn_hidden_dim), hidden_state
 
     def _sequence_features(self, embedding, batch, steps):
@@ -138,13 +138,13 @@ class SharedActor(_Trunk):
         self.GRU = nn.GRU(rnn_input_dim, rnn_hidden_dim, num_layers)
         self.Mean = _make_linear(rnn_hidden_dim, action_dim, is_sn)
 
-    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None):
+    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, inplace_hidden=False):
         """mode 0 (one step for R environments): returns prob (R,P,A), hidden, embedding (R,P,E)   (:422-425)
         mode 1 (sequences, rows ordered (episode, step)): returns prob (batch,steps,P,A), None, embedding  (:426-437)"""
         emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], obs["o_adj"], hist,
                               False, None, obs.get("q_div", 1))
         if mode == 0:
-            feat, hidden_state = self._rollout_features(emb, hidden_state)
+            feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)
         else:
             feat, hidden_state = self._sequence_features(emb, batch, steps), None
         prob = torch.softmax(self.Mean(feat), dim=-1)
@@ -168,12 +168,12 @@ class SharedCritic(_Trunk):
         head = _ortho_linear(rnn_hidden_dim, value_dim)
         self.Mean = spectral_norm(head) if is_sn else head  # the only spectrally normalised layer (:485)
 
-    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, rollout=False):
+    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, rollout=False, inplace_hidden=False):
         kvalid = obs.get("o_kvalid") if rollout else None
         emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], obs["o_adj"], hist,
                               True, kvalid, obs.get("q_div", 1))
         if mode == 0:
-            feat, hidden_state = self._rollout_features(emb, hidden_state)
+            feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)
             return self.Mean(feat), hidden_state, emb
         feat = self._sequence_features(emb, batch, steps)
         return self.Mean(feat)

@@ -14,7 +14,7 @@ from . import build as _build
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record",
            "mappo_ops_error_string")
 
 _lib = None
@@ -50,6 +50,7 @@ def load_library():
         L.wgrad_tn_workspace.argtypes = [i32, i32]
         L.wgrad_tn_workspace.restype = i64
         L.wgrad_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
+        L.rollout_record.argtypes = [i32, i32, vp, vp, vp, i32, vp]
         L.mappo_ops_error_string.argtypes = [C.c_int]
         L.mappo_ops_error_string.restype = C.c_char_p
         _lib = L
@@ -293,6 +294,31 @@ def linear(x, W, b=None):
 
 
 FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel
+class RecordItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_row_stride", C.c_int64), ("row_bytes", C.c_int32), ("i32_to_f32", C.c_int32)]
+
+
+def rollout_record(pairs, raw=None, episode_return=None):
+    """pairs: (src, dst) tensors; src dense (N, ...), dst a row-strided view of the same trailing shape (buffer[k][rows, t]).
+    One launch for all of them (csrc/mappo_ops.hip k_rollout_record); int32 sources are converted to dst's float32."""
+    L = load_library()
+    n = len(pairs)
+    arr = (RecordItem * max(n, 1))()
+    N = pairs[0][0].shape[0]
+    for k, (src, dst) in enumerate(pairs):
+        _need_gpu(src, "rollout_record")
+        assert src.is_contiguous() and src.shape == dst.shape and src.shape[0] == N and (N == 1 or dst[0].is_contiguous())
+        conv = src.dtype == torch.int32 and dst.dtype == torch.float32
+        assert conv or src.dtype == dst.dtype
+        it = arr[k]
+        it.src, it.dst = src.data_ptr(), dst.data_ptr()
+        it.row_bytes = src[0].numel() * src.element_size()
+        it.dst_row_stride = dst.stride(0) * dst.element_size()
+        it.i32_to_f32 = int(conv)
+    P = raw.shape[1] if raw is not None else 0
+    _check(L.rollout_record(N, n, C.cast(arr, C.c_void_p), _ptr(raw), _ptr(episode_return), P, _stream()), "rollout_record")
+
+
 PERSISTENT_GRU_MIN_T = 2  # sequences at least this long take the one-launch recurrence (H = 128)
 
 
@@ -371,9 +397,11 @@ class _GRULayer(torch.autograd.Function):
         return dx, dcarry, dw_ih, dw_hh, db_ih, db_hh
 
 
-def gru(x, h0, gru_module):
+def gru(x, h0, gru_module, inplace_hidden=False):
     """torch.nn.GRU(x, h0) semantics (seq-first, unidirectional, no dropout) on the fused path.
-    x (T, B, I), h0 (num_layers, B, H) -> out (T, B, H), h_n (num_layers, B, H)."""
+    x (T, B, I), h0 (num_layers, B, H) -> out (T, B, H), h_n (num_layers, B, H).
+    inplace_hidden (single rollout step only): the new hidden state overwrites h0 (each 16-row tile is read before it is
+    written by the one workgroup that owns it) and h_n IS h0 -- no stack, no copy back into the rollout state."""
     hn = []
     inp = x
     T, B = x.shape[0], x.shape[1]
@@ -383,7 +411,8 @@ def gru(x, h0, gru_module):
         if T == 1 and not torch.is_grad_enabled() and w_hh.shape[1] == 128 and w_ih.shape[1] == 128 and B >= FUSED_CELL_MIN_ROWS:
             # rollout step: both projections + gates in one persistent launch (csrc/mappo_ops.hip k_gru_cell)
             _need_gpu(inp, "gru")
-            out = torch.empty((1, B, 128), dtype=inp.dtype, device=inp.device)
+            inplace = inplace_hidden and h0.is_contiguous()
+            out = h0[layer].unsqueeze(0) if inplace else torch.empty((1, B, 128), dtype=inp.dtype, device=inp.device)
             _check(load_library().gru_cell_fwd(B, 128, _ptr(inp.contiguous()), _ptr(h0[layer].contiguous()), _ptr(w_ih.detach().contiguous()),
                                                _ptr(w_hh.detach().contiguous()), _ptr(b_ih.detach().contiguous()),
                                                _ptr(b_hh.detach().contiguous()), _ptr(out), _stream()), "gru_cell_fwd")
@@ -391,4 +420,6 @@ def gru(x, h0, gru_module):
         else:
             inp = _GRULayer.apply(inp, h0[layer], w_ih, w_hh, b_ih, b_hh)
         hn.append(inp[-1])
+    if all(t.data_ptr() == h0[k].data_ptr() for k, t in enumerate(hn)):
+        return inp, h0
     return inp, torch.stack(hn, 0)

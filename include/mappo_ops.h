@@ -110,6 +110,23 @@ int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, cons
                  const float *b_hh, float *h_out, void *stream);
 
 /*
+ * Records one rollout tick into the replay buffer (MAPPO.run_episode's minibuffer.store_transition,
+ * DHGN/mappo_parallel.py:783-805, for N environments at once): for every item, row n of the dense [N][row_bytes] source
+ * goes to dst + n * dst_row_stride (slot [n, t] of an (N, T, ...) buffer tensor); i32_to_f32 converts int32 actions to
+ * the buffer's float32.  If raw != NULL, episode_return[n] += sum_p raw[n][p] (the evaluator's episode reward).
+ * The item array is read on the host at call time.
+ */
+#define MO_RECORD_MAX_ITEMS 16
+typedef struct {
+    const void *src;
+    void *dst;
+    int64_t dst_row_stride; /* bytes between consecutive environments in dst */
+    int32_t row_bytes;      /* multiple of 4 */
+    int32_t i32_to_f32;
+} mo_record_item;
+int rollout_record(int32_t N, int32_t n_items, const mo_record_item *items, const float *raw, float *episode_return, int32_t P, void *stream);
+
+/*
  * Weight gradient of a Linear / GRU projection, C = A^T B reduced over all K rows of a minibatch:
  *   C [M][N] (dense) = (accumulate ? C : 0) + sum_k A[k][:]^T B[k][:] ;  A [K][M] (lda), B [K][N] (ldb), row-major fp32.
  * Replaces the `grad_output.t() @ input` GEMMs autograd runs for torch.nn.Linear / torch.nn.GRU weights in
