@@ -326,19 +326,23 @@ class _RolloutState:
         else:
             hops_a = hops_c = []
         o = self._obs()
-        prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True)
-        v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True)
+        # every result lands directly in the static rollout storage (no copies behind the model)
+        prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True, emb_out=self.a_cur)
+        v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True, emb_out=self.c_cur)  # the value head stays a module call (spectral-norm hook)
         if forced_actions is not None:
-            a_n = forced_actions.to(torch.int32)
-            logp = torch.distributions.Categorical(probs=prob).log_prob(forced_actions)
+            self.a_n.copy_(forced_actions.to(torch.int32))
+            self.logp.copy_(torch.distributions.Categorical(probs=prob).log_prob(forced_actions))
         else:
-            a_n, logp = ops.categorical_sample(prob, ag.sample_seed, 0, counter=self.counter)
+            ops.categorical_sample(prob, ag.sample_seed, 0, counter=self.counter, out=(self.a_n, self.logp))
         if ha is not self.ha:
             self.ha.copy_(ha)
         if hc is not self.hc:
             self.hc.copy_(hc)
-        self.a_cur.copy_(a_emb); self.c_cur.copy_(c_emb)
-        self.a_n.copy_(a_n); self.logp.copy_(logp); self.v.copy_(v.reshape(self.N, self.P))
+        if a_emb.data_ptr() != self.a_cur.data_ptr():
+            self.a_cur.copy_(a_emb)
+        if c_emb.data_ptr() != self.c_cur.data_ptr():
+            self.c_cur.copy_(c_emb)
+        self.v.copy_(v.reshape(self.N, self.P))
 
     def value_step(self):
         ag, d = self.agent, self.d

@@ -60,7 +60,7 @@ class DHGN(nn.Module):
             self.AGG_layers[f"AGG_fcra_{k}"] = _make_linear(E, E, is_sn)
 
     # -- encoder (:241-304) ----------------------------------------------------------------------------
-    def encoder(self, p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid=None, q_div=1):
+    def encoder(self, p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid=None, q_div=1, out=None):
         """p (R,P,4), e (R,1,4), o (R/q_div,O,4), adj_* (R,P,{P,1,O}) -> h0 (R,P,E).
         is_critic: adjacency := ones (AttributeDataset, :64-65); in a batched rollout the obstacle relation uses ones
         over the first o_kvalid[row] (real) obstacles, in training over all padded slots."""
@@ -73,11 +73,13 @@ class DHGN(nn.Module):
         emb = F.relu(ops.linear(m3, agg0.weight, agg0.bias))                          # one GEMM for the three relations
         # semantic_layer([p, emb0, emb1, emb2]) without materialising the concatenation (:284-303)
         Ws = self.semantic_layer.weight
-        h0 = ops.linear(emb.reshape(R * P, 3 * E), Ws[:, ind:]) + F.linear(p.reshape(R * P, ind), Ws[:, :ind], self.semantic_layer.bias)
+        # the position part (K = 4) first, the embedding part accumulates onto it in its GEMM epilogue (beta = 1)
+        small = F.linear(p.reshape(R * P, ind), Ws[:, :ind], self.semantic_layer.bias)
+        h0 = ops.linear(emb.reshape(R * P, 3 * E), Ws[:, ind:], small, out=None if out is None else out.view(R * P, E))
         return h0.reshape(R, P, E)
 
     # -- fixed-depth recursive aggregation over neighbours' historical embeddings (:204-233) --------------
-    def fcra(self, h0, hist, adj_p, is_critic):
+    def fcra(self, h0, hist, adj_p, is_critic, out=None):
         """hist: sequence of `depth` tensors (R,P,E), hop k = hist[k] (k = 0 is the most recent)."""
         h = h0
         E = self.embedding_dim
@@ -89,12 +91,14 @@ class DHGN(nn.Module):
             aggk = self.AGG_layers[f"AGG_fcra_{k}"]
             agg = F.relu(ops.linear(torch.matmul(abar, hist[k]), aggk.weight, aggk.bias))
             Wf = self.FCRA_layers[k].weight  # FCRA_k([agg, h]) as two accumulating GEMMs instead of a concatenation
-            h = F.relu(ops.linear(agg, Wf[:, :E]) + ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias))
+            pre = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias))
+            h = torch.clamp_min(pre, 0.0, out=out) if (out is not None and k == self.depth - 1) else F.relu(pre)
         return h
 
-    def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1):
-        h0 = self.encoder(p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid, q_div)
-        return self.fcra(h0, hist, adj_p, is_critic)
+    def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):
+        """out (R,P,E), rollout only: the embedding is written into it (static storage of the captured tick program)."""
+        h0 = self.encoder(p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid, q_div, out if self.depth == 0 else None)
+        return self.fcra(h0, hist, adj_p, is_critic, out)
 
 
 class _Trunk(nn.Module):
@@ -138,11 +142,11 @@ class SharedActor(_Trunk):
         self.GRU = nn.GRU(rnn_input_dim, rnn_hidden_dim, num_layers)
         self.Mean = _make_linear(rnn_hidden_dim, action_dim, is_sn)
 
-    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, inplace_hidden=False):
+    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, inplace_hidden=False, emb_out=None):
         """mode 0 (one step for R environments): returns prob (R,P,A), hidden, embedding (R,P,E)   (:422-425)
         mode 1 (sequences, rows ordered (episode, step)): returns prob (batch,steps,P,A), None, embedding  (:426-437)"""
         emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], obs["o_adj"], hist,
-                              False, None, obs.get("q_div", 1))
+                              False, None, obs.get("q_div", 1), emb_out)
         if mode == 0:
             feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)
         else:
@@ -168,10 +172,11 @@ class SharedCritic(_Trunk):
         head = _ortho_linear(rnn_hidden_dim, value_dim)
         self.Mean = spectral_norm(head) if is_sn else head  # the only spectrally normalised layer (:485)
 
-    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, rollout=False, inplace_hidden=False):
+    def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, rollout=False, inplace_hidden=False,
+                emb_out=None):
         kvalid = obs.get("o_kvalid") if rollout else None
         emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], obs["o_adj"], hist,
-                              True, kvalid, obs.get("q_div", 1))
+                              True, kvalid, obs.get("q_div", 1), emb_out)
         if mode == 0:
             feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)
             return self.Mean(feat), hidden_state, emb

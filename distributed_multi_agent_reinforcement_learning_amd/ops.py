@@ -213,7 +213,7 @@ def gae_advnorm(r, v, active, gamma, lamda, use_adv_norm=True):
     return adv, v_target
 
 
-def categorical_sample(probs, seed, offset, greedy=False, counter=None):
+def categorical_sample(probs, seed, offset, greedy=False, counter=None, out=None):
     """Categorical(probs).sample() and log_prob, or argmax when greedy (reference DHGN/mappo_parallel.py:442-448).
     `counter` (int64 device tensor of one element) replaces the host-side offset: the stream position lives on the
     device and advances by the number of rows, which makes the call replayable inside a captured graph."""
@@ -223,8 +223,13 @@ def categorical_sample(probs, seed, offset, greedy=False, counter=None):
     A = probs.shape[-1]
     pr = probs.reshape(-1, A).contiguous()
     R = pr.shape[0]
-    action = torch.empty(R, dtype=torch.int32, device=probs.device)
-    logp = torch.empty(R, dtype=torch.float32, device=probs.device)
+    if out is not None:  # (action int32, logp float32) dense tensors of `shape`, written in place (static rollout storage)
+        action, logp = out
+        assert action.dtype == torch.int32 and logp.dtype == torch.float32 and action.is_contiguous() and logp.is_contiguous()
+        assert action.numel() == R and logp.numel() == R
+    else:
+        action = torch.empty(R, dtype=torch.int32, device=probs.device)
+        logp = torch.empty(R, dtype=torch.float32, device=probs.device)
     if counter is not None:
         assert counter.dtype == torch.int64 and counter.numel() == 1 and counter.is_cuda
         _check(L.categorical_sample_counter(R, A, _ptr(pr), int(seed), _ptr(counter), 1 if greedy else 0, _ptr(action), _ptr(logp),
@@ -266,14 +271,24 @@ def wgrad(a, b, out=None, accumulate=False):
     return out
 
 
+def _linear_fwd(x, W, b, out=None):
+    """x W^T + b; b is a bias (out,) or a full addend of the output's shape (the add rides in the GEMM epilogue, beta = 1)"""
+    if b is None:
+        y = torch.mm(x.reshape(-1, W.shape[1]), W.t(), out=out)
+    else:
+        y = torch.addmm(b if b.dim() == 1 else b.reshape(-1, W.shape[0]), x.reshape(-1, W.shape[1]), W.t(), out=out)
+    return y.reshape(x.shape[:-1] + (W.shape[0],))
+
+
 class _Linear(torch.autograd.Function):
-    """F.linear whose weight gradient runs in the split-K MFMA kernel (wgrad)."""
+    """x W^T + b whose weight gradient runs in the split-K MFMA kernel (wgrad)."""
 
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
-        ctx.has_bias = b is not None
-        return F.linear(x, W, b)
+        ctx.bias_kind = 0 if b is None else (1 if b.dim() == 1 else 2)
+        ctx.b_shape = None if b is None else b.shape
+        return _linear_fwd(x, W, b)
 
     @staticmethod
     def backward(ctx, g):
@@ -282,15 +297,19 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, W.shape[1])
         dx = torch.mm(g2, W).reshape(x.shape) if ctx.needs_input_grad[0] else None
         dW = wgrad(g2, x2) if ctx.needs_input_grad[1] else None
-        db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.bias_kind and ctx.needs_input_grad[2]:
+            db = g2.sum(0) if ctx.bias_kind == 1 else g.reshape(ctx.b_shape)
         return dx, dW, db
 
 
-def linear(x, W, b=None):
-    """F.linear(x, W, b) (W may be a column slice of a larger weight); under autograd the weight gradient uses wgrad."""
-    if torch.is_grad_enabled() and (W.requires_grad or x.requires_grad):
+def linear(x, W, b=None, out=None):
+    """F.linear(x, W, b) (W may be a column slice of a larger weight; b a bias or a full addend); under autograd the weight
+    gradient uses wgrad.  out (2-D, no autograd): written in place."""
+    if torch.is_grad_enabled() and (W.requires_grad or x.requires_grad or (b is not None and b.requires_grad)):
+        assert out is None
         return _Linear.apply(x, W, b)
-    return F.linear(x, W, b)
+    return _linear_fwd(x, W, b, out)
 
 
 FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel
