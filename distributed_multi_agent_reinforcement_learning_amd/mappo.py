@@ -136,6 +136,8 @@ class MAPPO:
         self.reference_quirks = bool(rt.get("reference_quirks", True))
         self.sample_seed = int(rt.get("seed", 0))
         self.use_graphs = bool(rt.get("use_graphs", True))
+        self.overlap_actor_critic = bool(rt.get("overlap_actor_critic", True))  # update: critic branch on a second HIP stream
+        self._side_stream = None
         self.last_adv = self.last_v_target = None
 
     # ---- update (:638-723) ------------------------------------------------------------------------------------
@@ -162,8 +164,24 @@ class MAPPO:
             # EmbeddingDataset2 (:95-113): hop k reads the stored embeddings of step t-1-k (clean per-net history)
             hist_a = [batch["actor_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
             hist_c = [batch["critic_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
-            a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
-            values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
+            # The actor and the critic branch share nothing but the encoder weights until the loss: the critic runs on a
+            # second stream (forward here, its backward nodes follow it there), which fills the CUs / MFMA slots the
+            # persistent GRU kernels (205 workgroups, serial over T) leave idle.
+            if self.overlap_actor_critic:
+                main = torch.cuda.current_stream()
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream()
+                    warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                    if warn_off is not None:
+                        warn_off(False)  # the shared encoder's AccumulateGrad nodes see both streams on purpose
+                self._side_stream.wait_stream(main)
+                with torch.cuda.stream(self._side_stream):
+                    values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
+                a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
+                main.wait_stream(self._side_stream)
+            else:
+                a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
+                values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
             active = batch["active"][n0:n1]
             ratios = torch.exp(a_logprob_n_now - batch["a_logprob_n"][n0:n1].detach())
             surr1 = ratios * adv[n0:n1]
@@ -181,9 +199,10 @@ class MAPPO:
             (actor_loss + critic_loss).backward()
             if self.use_grad_clip:  # on the gradients accumulated so far, after every mini-batch
                 torch.nn.utils.clip_grad_norm_(self.ac_parameters, 5.0)
-            object_critics += critic_loss.item()
-            object_actors += actor_loss.item()
+            object_critics = object_critics + critic_loss.detach().double()   # f64 sum on the device: no host sync per mini-batch
+            object_actors = object_actors + actor_loss.detach().double()
             update_time += 1
+        object_critics, object_actors = float(object_critics), float(object_actors)
         if self.use_lr_decay:
             self.lr_decay(total_steps)
         if not return_grads:  # device-side path: gradients stay in .grad for the flat all-reduce

@@ -84,7 +84,7 @@ _workspaces = {}
 
 
 def _workspace(device, E, din):
-    key = (device, E, din)
+    key = (device, E, din, torch.cuda.current_stream().cuda_stream)  # per stream: actor and critic backward may overlap
     ws = _workspaces.get(key)
     if ws is None:
         n = load_library().dhgn_msg_agg_bwd_workspace(E, din)
