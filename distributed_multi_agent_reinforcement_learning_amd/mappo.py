@@ -136,7 +136,10 @@ class MAPPO:
         self.reference_quirks = bool(rt.get("reference_quirks", True))
         self.sample_seed = int(rt.get("seed", 0))
         self.use_graphs = bool(rt.get("use_graphs", True))
-        self.overlap_actor_critic = bool(rt.get("overlap_actor_critic", True))  # update: critic branch on a second HIP stream
+        # update: critic branch on a second HIP stream.  Off by default: worth ~3 % on cfg2, but with DHGN depth > 0 (cfg3, 4096
+        # envs) the two branches' library GEMMs run concurrently and the update stops making progress (suspected: the BLAS
+        # handle's workspace / Stream-K flags are shared between the streams) -- our own kernels have no such shared state.
+        self.overlap_actor_critic = bool(rt.get("overlap_actor_critic", False))
         self._side_stream = None
         self.last_adv = self.last_v_target = None
 

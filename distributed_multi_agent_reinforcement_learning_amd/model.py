@@ -70,7 +70,7 @@ class DHGN(nn.Module):
         m3 = ops.msg_agg3(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
                           is_critic, o_kvalid, q_div)                                  # (R, P, 3, E)
         agg0 = self.AGG_layers["AGG_vertex_0"]
-        emb = F.relu(ops.linear(m3, agg0.weight, agg0.bias))                          # one GEMM for the three relations
+        emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)                       # one GEMM (+relu epilogue) for the three relations
         # semantic_layer([p, emb0, emb1, emb2]) without materialising the concatenation (:284-303)
         Ws = self.semantic_layer.weight
         # the position part (K = 4) first, the embedding part accumulates onto it in its GEMM epilogue (beta = 1)
@@ -89,10 +89,10 @@ class DHGN(nn.Module):
         abar = F.normalize(adj, p=1, dim=-1)
         for k in range(self.depth):
             aggk = self.AGG_layers[f"AGG_fcra_{k}"]
-            agg = F.relu(ops.linear(torch.matmul(abar, hist[k]), aggk.weight, aggk.bias))
+            agg = ops.linear(torch.matmul(abar, hist[k]), aggk.weight, aggk.bias, relu=True)
             Wf = self.FCRA_layers[k].weight  # FCRA_k([agg, h]) as two accumulating GEMMs instead of a concatenation
-            pre = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias))
-            h = torch.clamp_min(pre, 0.0, out=out) if (out is not None and k == self.depth - 1) else F.relu(pre)
+            h = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias), relu=True,
+                           out=out if k == self.depth - 1 else None)
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):

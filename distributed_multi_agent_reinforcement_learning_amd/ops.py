@@ -271,8 +271,15 @@ def wgrad(a, b, out=None, accumulate=False):
     return out
 
 
-def _linear_fwd(x, W, b, out=None):
-    """x W^T + b; b is a bias (out,) or a full addend of the output's shape (the add rides in the GEMM epilogue, beta = 1)"""
+def _linear_fwd(x, W, b, out=None, relu=False):
+    """x W^T + b; b is a bias (out,) or a full addend of the output's shape (the add rides in the GEMM epilogue, beta = 1);
+    relu with a 1-D bias rides in the hipBLASLt epilogue as well (bit-identical to relu(linear))."""
+    if relu:
+        if b is not None and b.dim() == 1 and out is None:
+            y = torch._addmm_activation(b, x.reshape(-1, W.shape[1]), W.t(), use_gelu=False)
+            return y.reshape(x.shape[:-1] + (W.shape[0],))
+        y = _linear_fwd(x, W, b)
+        return torch.clamp_min(y, 0.0, out=out.view(y.shape) if out is not None else None)
     if b is None:
         y = torch.mm(x.reshape(-1, W.shape[1]), W.t(), out=out)
     else:
@@ -284,15 +291,19 @@ class _Linear(torch.autograd.Function):
     """x W^T + b whose weight gradient runs in the split-K MFMA kernel (wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
-        ctx.save_for_backward(x, W)
+    def forward(ctx, x, W, b, relu):
         ctx.bias_kind = 0 if b is None else (1 if b.dim() == 1 else 2)
         ctx.b_shape = None if b is None else b.shape
-        return _linear_fwd(x, W, b)
+        ctx.relu = relu
+        y = _linear_fwd(x, W, b, None, relu)
+        ctx.save_for_backward(x, W, y if relu else None)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, W = ctx.saved_tensors
+        x, W, y = ctx.saved_tensors
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0.0)  # relu'(pre-activation) from the saved output
         g2 = g.reshape(-1, W.shape[0])
         x2 = x.reshape(-1, W.shape[1])
         dx = torch.mm(g2, W).reshape(x.shape) if ctx.needs_input_grad[0] else None
@@ -300,16 +311,16 @@ class _Linear(torch.autograd.Function):
         db = None
         if ctx.bias_kind and ctx.needs_input_grad[2]:
             db = g2.sum(0) if ctx.bias_kind == 1 else g.reshape(ctx.b_shape)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
-def linear(x, W, b=None, out=None):
-    """F.linear(x, W, b) (W may be a column slice of a larger weight; b a bias or a full addend); under autograd the weight
-    gradient uses wgrad.  out (2-D, no autograd): written in place."""
+def linear(x, W, b=None, out=None, relu=False):
+    """F.linear(x, W, b), optionally followed by relu (W may be a column slice of a larger weight; b a bias or a full
+    addend); under autograd the weight gradient uses wgrad.  out (no autograd): written in place."""
     if torch.is_grad_enabled() and (W.requires_grad or x.requires_grad or (b is not None and b.requires_grad)):
         assert out is None
-        return _Linear.apply(x, W, b)
-    return _linear_fwd(x, W, b, out)
+        return _Linear.apply(x, W, b, relu)
+    return _linear_fwd(x, W, b, out, relu)
 
 
 FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel

@@ -236,3 +236,27 @@ def test_rollout_record_matches_tensor_copies():
         want[2:2 + N, 3] = s.float()
         assert torch.equal(b, want)
     torch.testing.assert_close(ret, 1.0 + raw.sum(-1), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("full_addend", [False, True])
+def test_linear_relu_autograd_matches_torch(full_addend):
+    """ops.linear(..., relu=True): relu in the GEMM epilogue (1-D bias) or behind an accumulating GEMM (full addend)"""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.randn((8192, 128), generator=g, device="cuda", requires_grad=True)
+    W = torch.randn((128, 128), generator=g, device="cuda", requires_grad=True)
+    b = torch.randn((8192, 128) if full_addend else (128,), generator=g, device="cuda", requires_grad=True)
+    gout = torch.randn((8192, 128), generator=g, device="cuda")
+    y = ops.linear(x, W, b, relu=True)
+    y.backward(gout)
+    got = (y.detach().clone(), x.grad.clone(), W.grad.clone(), b.grad.clone())
+    x.grad = W.grad = b.grad = None
+    y2 = torch.relu(torch.nn.functional.linear(x, W) + b)
+    y2.backward(gout)
+    for u, v in zip(got, (y2.detach(), x.grad, W.grad, b.grad)):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=2e-3)
+    with torch.no_grad():
+        out = torch.empty_like(y2)
+        z = ops.linear(x, W, b, relu=True, out=out if full_addend else None)
+        torch.testing.assert_close(z, y2.detach(), rtol=1e-5, atol=1e-4)
