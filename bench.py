@@ -91,6 +91,25 @@ def measure_compute_kernels(trainer, cfg):
         out["gru_seq_fwd"] = {"bound": "mfma", "kernel": "k_gru_seq_fwd (recurrent GEMM h W_hh^T + gates, T steps in one launch)",
                               "achieved": round(fl / t / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4),
                               "us_per_launch": round(t * 1e6, 1), "rows": B, "steps": T}
+        Kr = mb * T * P  # rows of one mini-batch: the weight gradient of a GRU projection reduces over all of them
+        ga = torch.randn(Kr, 384, device=dev); xa = torch.randn(Kr, 128, device=dev)
+        t = timeit(lambda: ops.wgrad(ga, xa))
+        fl = 2.0 * Kr * 384 * 128
+        out["wgrad"] = {"bound": "mfma", "kernel": "k_wgrad<3,1> + reduce (dW_ih [384][128] = dgi^T x over the mini-batch rows, split-K)",
+                        "achieved": round(fl / t / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4),
+                        "us_per_launch": round(t * 1e6, 1), "rows": Kr, "hbm_GBps": round((384 + 128) * 4.0 * Kr / t / 1e9, 1)}
+        del ga, xa
+        Br = trainer.num_envs * P
+        from types import SimpleNamespace  # raw tensors: constructing torch.nn.GRU on the device initialises MIOpen
+        gm = SimpleNamespace(num_layers=1, weight_ih_l0=torch.randn(384, 128, device=dev) * 0.08, weight_hh_l0=torch.randn(384, 128, device=dev) * 0.08,
+                             bias_ih_l0=torch.zeros(384, device=dev), bias_hh_l0=torch.zeros(384, device=dev))
+        xr = torch.randn(1, Br, 128, device=dev); hr = torch.randn(1, Br, 128, device=dev)
+        with torch.no_grad():
+            t = timeit(lambda: ops.gru(xr, hr, gm), n=20)
+        fl = 2.0 * Br * 128 * 768
+        out["gru_cell"] = {"bound": "mfma", "kernel": "k_gru_cell (one rollout GRU layer step: both projections + gates, one launch)",
+                           "achieved": round(fl / t / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4),
+                           "us_per_launch": round(t * 1e6, 1), "rows": Br}
     R = mb * T
     p = torch.rand(R, P, 4, device=dev) * 40; q = torch.rand(mb, O, 4, device=dev) * 40
     W = torch.randn(E, 4, device=dev) * 0.3; bb = torch.zeros(E, device=dev)
