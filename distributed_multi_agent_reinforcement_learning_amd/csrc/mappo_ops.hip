@@ -587,19 +587,38 @@ __global__ __launch_bounds__(512) void k_gru_seq_bwd(int T, int B, const float *
     for (int kk = 0; kk < 96; kk++) wb[kk] = w_hh[(size_t)(4 * kk + q) * GRU_H + j];  // B[k][n = j]
     const size_t BH = (size_t)B * GRU_H;
     float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
+    // The saved gates, h_{t-1} and dout of a step do not depend on the recurrence: they are loaded one step ahead (24
+    // registers), so their HBM latency hides behind the MFMA phase instead of stalling the head of every step.
+    float pr[4], pz[4], pn[4], phn[4], php[4], pdo[4];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = 4 * q + reg;
+            pr[reg] = pz[reg] = pn[reg] = phn[reg] = php[reg] = pdo[reg] = 0.f;
+            if (b0 + row < B) {
+                const size_t o = (size_t)(b0 + row) * GRU_H + j;
+                const float *sv = save + (size_t)t * 4 * BH;
+                pr[reg] = sv[o]; pz[reg] = sv[BH + o]; pn[reg] = sv[2 * BH + o]; phn[reg] = sv[3 * BH + o];
+                php[reg] = t > 0 ? out[(size_t)(t - 1) * BH + o] : h0[o];
+                pdo[reg] = dout[(size_t)t * BH + o];
+            }
+        }
+    };
+    prefetch(T - 1);
     for (int t = T - 1; t >= 0; t--) {
-        float dhz[4];
+        float dhz[4], cr[4], cz[4], cn[4], chn[4], chp[4], cdo[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) { cr[reg] = pr[reg]; cz[reg] = pz[reg]; cn[reg] = pn[reg]; chn[reg] = phn[reg]; chp[reg] = php[reg]; cdo[reg] = pdo[reg]; }
+        if (t > 0) prefetch(t - 1);
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int row = 4 * q + reg;
             float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f;
             dhz[reg] = 0.f;
             if (b0 + row < B) {
-                const size_t o = (size_t)(b0 + row) * GRU_H + j;
-                const float *sv = save + (size_t)t * 4 * BH;
-                const float r = sv[o], z = sv[BH + o], n = sv[2 * BH + o], hn = sv[3 * BH + o];
-                const float hp = t > 0 ? out[(size_t)(t - 1) * BH + o] : h0[o];
-                const float dh = dout[(size_t)t * BH + o] + dcarry[reg];
+                const float r = cr[reg], z = cz[reg], n = cn[reg], hn = chn[reg];
+                const float hp = chp[reg];
+                const float dh = cdo[reg] + dcarry[reg];
                 dn = dh * (1.f - z) * (1.f - n * n);
                 dz = dh * (hp - n) * z * (1.f - z);
                 dr = dn * hn * r * (1.f - r);
