@@ -692,6 +692,69 @@ int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, cons
 
 constexpr int BWD_BLOCKS = 1024;
 
+// ---- PPO policy / value loss of one mini-batch, forward and gradients in one pass (DHGN/mappo_parallel.py:692-706) -------
+// Element-wise fp32 arithmetic in torch's op order (so the values match the op-by-op graph), masked sums in f64 through
+// per-block partials (no atomics: deterministic).  The gradients w.r.t. logp_now / entropy / values_now are produced in the
+// same pass with autograd's tie rules: min / max send half the gradient to each side of an exact tie (inside the clip
+// range surr1 == surr2, and both halves reach the ratio), clamp passes the gradient on its closed range.
+constexpr int PPO_BLOCKS = 256;
+__global__ __launch_bounds__(256) void k_ppo_loss(long n, const float *lp_now, const float *ent, const float *lp_old, const float *adv,
+                                                  const float *active, const float *v_now, const float *v_old, const float *v_tgt,
+                                                  const float *active_sum, float eps, float ent_coef, int value_clip, float *g_lp,
+                                                  float *g_ent, float *g_v, double *partials) {
+    const float inv = 1.f / active_sum[0];
+    double sa = 0.0, sc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float act = active[i];
+        const float ratio = expf(lp_now[i] - lp_old[i]);
+        const float a = adv[i];
+        const float surr1 = ratio * a;
+        const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
+        const float surr2 = rc * a;
+        const float la = -fminf(surr1, surr2) - ent_coef * ent[i];
+        sa += (double)(la * act);
+        const bool inside = ratio >= 1.f - eps && ratio <= 1.f + eps;
+        const float w1 = surr1 < surr2 ? 1.f : (surr1 == surr2 ? 0.5f : 0.f);   // share of min() that flows to surr1
+        const float w2 = surr2 < surr1 ? 1.f : (surr1 == surr2 ? 0.5f : 0.f);   // ... to surr2 (reaches the ratio inside the clip range)
+        const float up = act * inv;                                               // d loss / d la
+        g_lp[i] = -up * (w1 + (inside ? w2 : 0.f)) * a * ratio;
+        g_ent[i] = -up * ent_coef;
+        const float eo = v_now[i] - v_tgt[i];
+        float lc, gv;
+        if (value_clip) {
+            const float d = v_now[i] - v_old[i];
+            const float dc = fminf(fmaxf(d, -eps), eps);
+            const float ec = (dc + v_old[i]) - v_tgt[i];
+            const float qa = ec * ec, qb = eo * eo;
+            lc = fmaxf(qa, qb);
+            const float wa = qa > qb ? 1.f : (qa == qb ? 0.5f : 0.f), wb = qb > qa ? 1.f : (qa == qb ? 0.5f : 0.f);
+            const bool din = d >= -eps && d <= eps;
+            gv = wa * 2.f * ec * (din ? 1.f : 0.f) + wb * 2.f * eo;
+        } else {
+            lc = eo * eo;
+            gv = 2.f * eo;
+        }
+        sc += (double)(lc * act);
+        g_v[i] = up * gv;
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = sa; red[1][threadIdx.x] = sc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = red[0][0]; partials[2 * blockIdx.x + 1] = red[1][0]; }
+}
+
+__global__ void k_ppo_loss_finish(int nblk, const double *partials, const float *active_sum, float *losses) {
+    if (threadIdx.x < 2) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; b++) s += partials[2 * b + threadIdx.x];
+        losses[threadIdx.x] = (float)s / active_sum[0];
+    }
+}
+
 // ---- per-tick recording of the rollout into the replay buffer ------------------------------------------------------------
 // One launch instead of ~10 strided tensor copies: workgroup n moves environment n's row of every item from the rollout's
 // static tensors into slot [n, t] of the (N, T, ...) buffer tensors (dst rows are dst_row_stride bytes apart), converts the
@@ -1035,6 +1098,24 @@ int rollout_record(int32_t N, int32_t n_items, const mo_record_item *items, cons
     a.ret = episode_return;
     a.P = P;
     hipLaunchKernelGGL(k_rollout_record, dim3(N), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int64_t ppo_loss_workspace(void) { return (int64_t)PPO_BLOCKS * 2 * sizeof(double); }
+
+int ppo_loss_fwd_bwd(int64_t n, const float *logp_now, const float *entropy, const float *logp_old, const float *adv, const float *active,
+                     const float *values_now, const float *values_old, const float *v_target, const float *active_sum, float epsilon,
+                     float entropy_coef, int32_t use_value_clip, float *losses, float *grad_logp, float *grad_entropy, float *grad_values,
+                     void *workspace, void *stream) {
+    if (n < 1 || !logp_now || !entropy || !logp_old || !adv || !active || !values_now || !v_target || !active_sum || !losses || !grad_logp ||
+        !grad_entropy || !grad_values || !workspace || (use_value_clip && !values_old))
+        return MO_ERR_BAD_ARG;
+    long blocks = (n + 255) / 256;
+    if (blocks > PPO_BLOCKS) blocks = PPO_BLOCKS;
+    hipLaunchKernelGGL(k_ppo_loss, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, logp_now, entropy, logp_old, adv, active,
+                       values_now, values_old, v_target, active_sum, epsilon, entropy_coef, (int)use_value_clip, grad_logp, grad_entropy,
+                       grad_values, (double *)workspace);
+    hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)blocks, (const double *)workspace, active_sum, losses);
     return (int)hipGetLastError();
 }
 

@@ -185,20 +185,9 @@ class MAPPO:
             else:
                 a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
                 values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
-            active = batch["active"][n0:n1]
-            ratios = torch.exp(a_logprob_n_now - batch["a_logprob_n"][n0:n1].detach())
-            surr1 = ratios * adv[n0:n1]
-            surr2 = torch.clamp(ratios, 1 - self.epsilon, 1 + self.epsilon) * adv[n0:n1]
-            actor_loss = -torch.min(surr1, surr2) - self.entropy_coef * dist_entropy
-            actor_loss = (actor_loss * active).sum() / active.sum()
-            if self.use_value_clip:
-                values_old = batch["v_n"][n0:n1, :-1].detach()
-                err_clip = torch.clamp(values_now - values_old, -self.epsilon, self.epsilon) + values_old - v_target[n0:n1]
-                err_orig = values_now - v_target[n0:n1]
-                critic_loss = torch.max(err_clip ** 2, err_orig ** 2)
-            else:
-                critic_loss = (values_now - v_target[n0:n1]) ** 2
-            critic_loss = (critic_loss * active).sum() / active.sum()
+            actor_loss, critic_loss = ops.ppo_loss(a_logprob_n_now, dist_entropy, values_now, batch["a_logprob_n"][n0:n1], adv[n0:n1],
+                                                   batch["active"][n0:n1], batch["v_n"][n0:n1, :-1] if self.use_value_clip else None,
+                                                   v_target[n0:n1], self.epsilon, self.entropy_coef, self.use_value_clip)
             (actor_loss + critic_loss).backward()
             if self.use_grad_clip:  # on the gradients accumulated so far, after every mini-batch
                 torch.nn.utils.clip_grad_norm_(self.ac_parameters, 5.0)

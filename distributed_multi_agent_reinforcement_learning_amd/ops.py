@@ -14,7 +14,7 @@ from . import build as _build
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -51,6 +51,8 @@ def load_library():
         L.wgrad_tn_workspace.restype = i64
         L.wgrad_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
         L.rollout_record.argtypes = [i32, i32, vp, vp, vp, i32, vp]
+        L.ppo_loss_workspace.restype = i64
+        L.ppo_loss_fwd_bwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp]
         L.mappo_ops_error_string.argtypes = [C.c_int]
         L.mappo_ops_error_string.restype = C.c_char_p
         _lib = L
@@ -324,6 +326,40 @@ def linear(x, W, b=None, out=None, relu=False):
 
 
 FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel
+class _PPOLoss(torch.autograd.Function):
+    """(actor_loss, critic_loss) of one mini-batch; the gradients are computed in the forward launch and scaled here."""
+
+    @staticmethod
+    def forward(ctx, logp_now, entropy, values_now, logp_old, adv, active, values_old, v_target, epsilon, entropy_coef, use_value_clip):
+        L = load_library()
+        _need_gpu(logp_now, "ppo_loss")
+        ts = [t.contiguous() for t in (logp_now, entropy, logp_old, adv, active, values_now, v_target)]
+        vo = values_old.contiguous() if values_old is not None else None
+        n = ts[0].numel()
+        assert all(t.numel() == n and t.dtype == torch.float32 for t in ts)
+        dev = logp_now.device
+        asum = active.sum().reshape(1)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        g = torch.empty((3,) + tuple(logp_now.shape), dtype=torch.float32, device=dev)
+        ws = torch.empty(L.ppo_loss_workspace(), dtype=torch.uint8, device=dev)
+        _check(L.ppo_loss_fwd_bwd(n, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]), _ptr(ts[4]), _ptr(ts[5]), _ptr(vo), _ptr(ts[6]),
+                                  _ptr(asum), float(epsilon), float(entropy_coef), int(bool(use_value_clip)), _ptr(losses), _ptr(g[0]),
+                                  _ptr(g[1]), _ptr(g[2]), _ptr(ws), _stream()), "ppo_loss_fwd_bwd")
+        ctx.save_for_backward(g)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, ga, gc):
+        (g,) = ctx.saved_tensors
+        return g[0] * ga, g[1] * ga, g[2] * gc, None, None, None, None, None, None, None, None
+
+
+def ppo_loss(logp_now, entropy, values_now, logp_old, adv, active, values_old, v_target, epsilon, entropy_coef, use_value_clip=True):
+    """Masked-mean PPO policy loss and (clipped) value loss of a mini-batch, one launch with the gradients
+    (DHGN/mappo_parallel.py:692-706; csrc/mappo_ops.hip k_ppo_loss)."""
+    return _PPOLoss.apply(logp_now, entropy, values_now, logp_old, adv, active, values_old, v_target, epsilon, entropy_coef, use_value_clip)
+
+
 class RecordItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_row_stride", C.c_int64), ("row_bytes", C.c_int32), ("i32_to_f32", C.c_int32)]
 

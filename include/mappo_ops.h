@@ -110,6 +110,22 @@ int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, cons
                  const float *b_hh, float *h_out, void *stream);
 
 /*
+ * PPO clipped-surrogate policy loss and clipped value loss of one mini-batch with their gradients
+ * (DHGN/mappo_parallel.py:692-706):
+ *   ratio = exp(logp_now - logp_old); actor = -min(ratio adv, clamp(ratio, 1-eps, 1+eps) adv) - entropy_coef entropy
+ *   critic = use_value_clip ? max((clamp(v_now - v_old, -eps, eps) + v_old - v_target)^2, (v_now - v_target)^2) : (v_now - v_target)^2
+ *   losses[0] = sum(actor * active) / active_sum ; losses[1] = sum(critic * active) / active_sum
+ * grad_* = d(losses[0] + losses[1]) / d(logp_now | entropy | values_now), autograd's tie rules for min / max / clamp.
+ * n elements (= episodes x T x P) per tensor, dense fp32; active_sum: device scalar sum(active); workspace >=
+ * ppo_loss_workspace() bytes.  Deterministic (f64 partial sums added in a fixed order).
+ */
+int64_t ppo_loss_workspace(void);
+int ppo_loss_fwd_bwd(int64_t n, const float *logp_now, const float *entropy, const float *logp_old, const float *adv, const float *active,
+                     const float *values_now, const float *values_old, const float *v_target, const float *active_sum, float epsilon,
+                     float entropy_coef, int32_t use_value_clip, float *losses, float *grad_logp, float *grad_entropy, float *grad_values,
+                     void *workspace, void *stream);
+
+/*
  * Records one rollout tick into the replay buffer (MAPPO.run_episode's minibuffer.store_transition,
  * DHGN/mappo_parallel.py:783-805, for N environments at once): for every item, row n of the dense [N][row_bytes] source
  * goes to dst + n * dst_row_stride (slot [n, t] of an (N, T, ...) buffer tensor); i32_to_f32 converts int32 actions to
