@@ -49,6 +49,8 @@ def load_config(path=None, **overrides):
     rt.setdefault("max_path", 128)
     rt.setdefault("reference_quirks", True)
     rt.setdefault("use_graphs", True)
+    rt.setdefault("device_reset", True)           # episode reset on the GPU (k_reset); False = host resetter, same results
+    rt.setdefault("overlap_actor_critic", False)  # update: critic branch on a second stream (see mappo.MAPPO)
     for k, v in overrides.items():
         node = cfg
         parts = k.split(".")

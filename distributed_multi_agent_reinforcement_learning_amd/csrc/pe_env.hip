@@ -823,6 +823,273 @@ int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, con
     return (int)hipGetLastError();
 }
 
+
+// ---- Pursuit_Env.reset on the device ---------------------------------------------------------------------
+// The host resetter (pe_reset.cpp) restated for one wavefront per environment: the same two generator streams (CPython
+// random = MT19937 + init_by_array + randbelow, numpy legacy RandomState = MT19937 + init_genrand + polar gauss), the same
+// draws in the same order, so an environment reset here starts exactly like one reset on the host (and like the
+// reference seeded with the same number).  The MT states live in HBM between episodes and in LDS during the launch;
+// lane 0 advances the streams and broadcasts every draw, so control flow stays wave-uniform; the grid work (block stamps,
+// inflation, inner boundary in argwhere order) runs on all lanes.  numpy's gauss goes through log(): the device libm is
+// within 1 ulp of glibc's, which can only matter if a block centre lands within 1 ulp of a rounding boundary.
+struct DevRng {
+    uint32_t py_mt[624], np_mt[624], snap_mt[624];
+    int32_t py_idx, np_idx, snap_idx, has_gauss, has_tape, pad;
+    double gauss;
+};
+
+__device__ uint32_t mt_next(uint32_t *mt, int &idx) {  // lane 0 only
+    if (idx >= 624) {
+        for (int k = 0; k < 624; k++) {
+            const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+__device__ uint32_t py_randbelow(uint32_t *mt, int &idx, uint32_t n) {  // random._randbelow_with_getrandbits
+    int k = 0;
+    for (uint32_t v = n; v; v >>= 1) k++;
+    uint32_t r = mt_next(mt, idx) >> (32 - k);
+    while (r >= n) r = mt_next(mt, idx) >> (32 - k);
+    return r;
+}
+__device__ double np_random_sample(uint32_t *mt, int &idx) {
+    const uint32_t a = mt_next(mt, idx) >> 5, b = mt_next(mt, idx) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+// base_env.py:52-70 on lane 0: first free cell of the inflated map
+__device__ void draw_target_l0(int W, int H, const uint8_t *infl, uint32_t *mt, int &idx, int &tx, int &ty) {
+    for (;;) {
+        tx = (int)py_randbelow(mt, idx, (uint32_t)W);
+        ty = (int)py_randbelow(mt, idx, (uint32_t)H);
+        if (infl[tx * H + ty] == 0) return;
+    }
+}
+
+__host__ __device__ inline size_t reset_lds_bytes(const pe_config &c) {
+    return align16(2 * 624 * sizeof(uint32_t)) + 3 * align16((size_t)c.W * c.H) + align16(sizeof(double) * 2 * PE_MAX_P) +
+           align16(sizeof(int32_t) * (2 * PE_MAX_P + 8));
+}
+
+__global__ __launch_bounds__(64) void k_reset(const pe_config c, const pe_state st, const pe_reset_params prm, DevRng *rng, uint8_t *infl_bank,
+                                              int first, int32_t *obs_xy, double *def_aos, float *o_state) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const int W = c.W, H = c.H, WH = W * H, P = c.P, O = c.O;
+    size_t off = 0;
+    uint32_t *pym = (uint32_t *)(smem + off); off += align16(624 * sizeof(uint32_t));
+    uint32_t *npm = (uint32_t *)(smem + off); off += align16(624 * sizeof(uint32_t));
+    uint8_t *grid = smem + off; off += align16(WH);
+    uint8_t *infl = smem + off; off += align16(WH);      // static inflation, then + the defenders' blocks
+    uint8_t *infs = smem + off; off += align16(WH);      // static inflation of this episode (target re-draws)
+    double *dxy = (double *)(smem + off); off += align16(sizeof(double) * 2 * PE_MAX_P);
+    int32_t *cells = (int32_t *)(smem + off);            // [2 * PE_MAX_P] unique rounded defender cells
+    DevRng &R = rng[env];
+    uint8_t *bank = infl_bank + (size_t)env * WH;
+    const bool rewind = !first && R.has_tape;
+    for (int i = lane; i < 624; i += WAVE) { pym[i] = rewind ? R.snap_mt[i] : R.py_mt[i]; npm[i] = R.np_mt[i]; }
+    int pyi = rewind ? R.snap_idx : R.py_idx, npi = R.np_idx;
+    int has_gauss = R.has_gauss;
+    double gauss = R.gauss;
+    if (rewind) for (int i = lane; i < WH; i += WAVE) infs[i] = bank[i];
+    wave_sync();
+    if (rewind && lane == 0) {  // the reference draws a new target only on arrival: give the unused tape draws back
+        const int consumed = st.meta[(size_t)env * PE_META_INTS + PE_META_TAPE_POS];
+        int tx, ty;
+        for (int k = 0; k < consumed; k++) draw_target_l0(W, H, infs, pym, pyi, tx, ty);
+    }
+    for (int i = lane; i < WH; i += WAVE) grid[i] = 0;
+    wave_sync();
+    // init_map -> add_blocker_type('r', (6, 7)): x, y in [-3, 3) around a normal(center, variance) point (Occupied_Grid_Map.py:46-62)
+    for (int b = 0; b < prm.num_blocks; b++) {
+        double cx = 0.0, cy = 0.0;
+        if (lane == 0) {
+            py_randbelow(pym, pyi, 1u);  // random.randrange(len(shape)) with one shape
+            double g2[2];
+            for (int q = 0; q < 2; q++) {
+                double v;
+                if (has_gauss) { has_gauss = 0; v = gauss; gauss = 0.0; }
+                else {
+                    double x1, x2, r2;
+                    do {
+                        x1 = 2.0 * np_random_sample(npm, npi) - 1.0;
+                        x2 = 2.0 * np_random_sample(npm, npi) - 1.0;
+                        r2 = x1 * x1 + x2 * x2;
+                    } while (r2 >= 1.0 || r2 == 0.0);
+                    const double f = __builtin_sqrt(-2.0 * log(r2) / r2);
+                    gauss = f * x1;
+                    has_gauss = 1;
+                    v = f * x2;
+                }
+                g2[q] = v;
+            }
+            cx = prm.center[0] + prm.variance * g2[0];
+            cy = prm.center[1] + prm.variance * g2[1];
+        }
+        cx = __shfl(cx, 0); cy = __shfl(cy, 0);
+        if (lane < 36) {
+            const int x = lane / 6 - 3, y = lane % 6 - 3;
+            const int px = py_round((double)x + cx), pyy = py_round((double)y + cy);
+            if (px >= 0 && px < W && pyy >= 0 && pyy < H) grid[px * H + pyy] = 1;
+        }
+        wave_sync();
+    }
+    for (int i = lane; i < WH; i += WAVE) {  // inflate every obstacle cell by 2 (Chebyshev)
+        const int x = i / H, y = i - x * H;
+        uint8_t v = 0;
+        for (int xx = x - 2; xx <= x + 2; xx++)
+            for (int yy = y - 2; yy <= y + 2; yy++)
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) v |= grid[xx * H + yy];
+        infl[i] = v; infs[i] = v;
+        bank[i] = v;
+        st.grid[(size_t)env * WH + i] = grid[i];
+    }
+    wave_sync();
+    // inner boundary (find_boundaries mode='inner', connectivity 1): obstacle cell with a free 4-neighbour, argwhere order
+    int n_obs = 0;
+    for (int base = 0; base < WH; base += WAVE) {
+        const int i = base + lane;
+        bool fr = false;
+        int x = 0, y = 0;
+        if (i < WH && grid[i]) {
+            x = i / H; y = i - x * H;
+            fr = (x > 0 && !grid[i - H]) || (x < W - 1 && !grid[i + H]) || (y > 0 && !grid[i - 1]) || (y < H - 1 && !grid[i + 1]);
+        }
+        const unsigned long long m = __ballot(fr);
+        const int pos = n_obs + __popcll(m & ((1ull << lane) - 1ull));
+        if (fr && pos < O) {
+            obs_xy[((size_t)env * O + pos) * 2] = x; obs_xy[((size_t)env * O + pos) * 2 + 1] = y;
+            if (o_state) { float4 v = make_float4((float)x, (float)y, 0.f, 0.f); ((float4 *)o_state)[(size_t)env * O + pos] = v; }
+        }
+        n_obs += __popcll(m);
+    }
+    for (int k = (n_obs < O ? n_obs : O) + lane; k < O; k += WAVE) {
+        obs_xy[((size_t)env * O + k) * 2] = 0; obs_xy[((size_t)env * O + k) * 2 + 1] = 0;
+        if (o_state) ((float4 *)o_state)[(size_t)env * O + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (lane == 0) st.n_obs[env] = n_obs;  // > O is reported to the caller (the reference's buffer would not fit it either)
+    {
+        int tx = 0, ty = 0;
+        if (lane == 0) {
+            draw_target_l0(W, H, infl, pym, pyi, tx, ty);
+            st.target[2 * env] = tx; st.target[2 * env + 1] = ty;
+        }
+    }
+    // init_defender (base_env.py:72-120)
+    int placed = 0, ncells = 0;
+    double *da = def_aos + (size_t)env * P * 4;
+    while (placed < P) {
+        double px = 0.0, pyv = 0.0;
+        if (lane == 0) { px = np_random_sample(npm, npi) * (double)(W - 1); pyv = np_random_sample(npm, npi) * (double)(H - 1); }
+        px = __shfl(px, 0); pyv = __shfl(pyv, 0);
+        const int cxi = py_round(px), cyi = py_round(pyv);
+        bool ok = false;
+        if (infl[cxi * H + cyi] == 0) {
+            if (placed == 0) {
+                ok = true;
+            } else {
+                double d = 0.0;
+                if (lane < placed) d = norm2(px - dxy[2 * lane], pyv - dxy[2 * lane + 1]);
+                const int collision = __popcll(__ballot(lane < placed && d < (double)prm.min_dist));
+                const int connectivity = __popcll(__ballot(lane < placed && d < c.def_comm_range));
+                ok = collision == 0 && connectivity > 0 && connectivity <= 2;
+            }
+        }
+        if (ok) {  // wave-uniform
+            bool seen = false;
+            for (int k = 0; k < ncells; k++) seen = seen || (cells[2 * k] == cxi && cells[2 * k + 1] == cyi);
+            wave_sync();
+            if (lane == 0) {
+                dxy[2 * placed] = px; dxy[2 * placed + 1] = pyv;
+                da[placed * 4] = px; da[placed * 4 + 1] = pyv; da[placed * 4 + 2] = 0.0; da[placed * 4 + 3] = 0.0;
+                if (!seen) { cells[2 * ncells] = cxi; cells[2 * ncells + 1] = cyi; }
+            }
+            if (lane < 25) {  // the new cell's 5 x 5 block (re-inflating the earlier cells as the reference does changes nothing)
+                const int xx = cxi + lane / 5 - 2, yy = cyi + lane % 5 - 2;
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) infl[xx * H + yy] = 1;
+            }
+            placed++;
+            if (!seen) ncells++;
+            wave_sync();
+        }
+    }
+    // init_attacker (base_env.py:122-162), is_percepted=True: free cell within sensing range of a defender cell
+    for (;;) {
+        double px = 0.0, pyv = 0.0;
+        if (lane == 0) { px = np_random_sample(npm, npi) * (double)(W - 1); pyv = np_random_sample(npm, npi) * (double)(H - 1); }
+        px = __shfl(px, 0); pyv = __shfl(pyv, 0);
+        if (infl[py_round(px) * H + py_round(pyv)] != 0) continue;
+        const bool hit = lane < ncells && norm2((double)cells[2 * lane] - px, (double)cells[2 * lane + 1] - pyv) < c.def_sen_range;
+        if (__ballot(hit) != 0ull) {
+            if (lane == 0) {
+                double *e = st.eva + (size_t)env * 4;
+                e[0] = px; e[1] = pyv; e[2] = 0.0; e[3] = 0.0;
+            }
+            break;
+        }
+    }
+    wave_sync();
+    // target tape: what init_target would return on the evader's next arrivals (pursuit_env.py:98-100); the stream position
+    // before the tape is kept so that the next reset can give the unused draws back
+    for (int i = lane; i < 624; i += WAVE) R.snap_mt[i] = pym[i];
+    if (lane == 0) {
+        R.snap_idx = pyi;
+        R.has_tape = 1;
+        int32_t *tape = st.tape + (size_t)env * c.tape_len * 2;
+        for (int k = 0; k < c.tape_len; k++) {
+            int tx, ty;
+            draw_target_l0(W, H, infs, pym, pyi, tx, ty);
+            tape[2 * k] = tx; tape[2 * k + 1] = ty;
+        }
+        R.py_idx = pyi; R.np_idx = npi; R.has_gauss = has_gauss; R.gauss = gauss;
+    }
+    wave_sync();
+    for (int i = lane; i < 624; i += WAVE) { R.py_mt[i] = pym[i]; R.np_mt[i] = npm[i]; }
+}
+
+// seeding: random.seed(s) (init_by_array) and np.random.seed(s) (init_genrand), one thread per environment
+__global__ void k_reset_seed(int N, const uint64_t *seeds, DevRng *rng) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    DevRng &R = rng[n];
+    const uint64_t a = seeds[n];
+    {
+        uint32_t *mt = R.np_mt;
+        mt[0] = (uint32_t)a;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        R.np_idx = 624;
+    }
+    {
+        uint32_t *mt = R.py_mt;
+        mt[0] = 19650218u;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        const uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+        const int len = key[1] ? 2 : 1;
+        int i = 1, j = 0;
+        for (int k = 624; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            i++; j++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (j >= len) j = 0;
+        }
+        for (int k = 623; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            i++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+        R.py_idx = 624;
+    }
+    R.snap_idx = 624; R.has_gauss = 0; R.has_tape = 0; R.pad = 0; R.gauss = 0.0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -841,6 +1108,58 @@ int pe_config_check(const pe_config *c) {
 
 int64_t pe_tick_lds_bytes(const pe_config *cfg, int32_t with_replan) {
     return (int64_t)lds_layout(*cfg, true, with_replan != 0, nullptr, nullptr);
+}
+
+int64_t pe_reset_state_bytes(const pe_config *cfg, int32_t N) {
+    if (!cfg || N < 1) return 0;
+    return (int64_t)N * ((int64_t)sizeof(DevRng) + (int64_t)cfg->W * cfg->H);
+}
+
+int pe_env_reset_seed(const pe_config *cfg, int32_t N, const uint64_t *seeds, void *reset_state, void *stream) {
+    if (!cfg || !seeds || !reset_state || N < 1) return PE_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    uint64_t *d_seeds = nullptr;
+    hipError_t e = hipMallocAsync((void **)&d_seeds, (size_t)N * sizeof(uint64_t), s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(d_seeds, seeds, (size_t)N * sizeof(uint64_t), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync((char *)reset_state + (size_t)N * sizeof(DevRng), 0, (size_t)N * cfg->W * cfg->H, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_reset_seed, dim3((N + 63) / 64), dim3(64), 0, s, (int)N, (const uint64_t *)d_seeds, (DevRng *)reset_state);
+    e = hipStreamSynchronize(s);  // the caller's seed array may go away
+    if (e != hipSuccess) return (int)e;
+    e = hipFreeAsync(d_seeds, s);
+    return e != hipSuccess ? (int)e : (int)hipGetLastError();
+}
+
+int pe_env_reset(const pe_config *cfg, const pe_state *st, const pe_reset_params *prm, void *reset_state, int32_t first, float *o_state,
+                 int32_t reset_rn, void *stream) {
+    if (!cfg || !st || !prm || !reset_state) return PE_ERR_NULL;
+    int rc = pe_config_check(cfg);
+    if (rc) return rc;
+    if (prm->num_blocks < 0 || prm->min_dist < 0) return PE_ERR_BAD_CONFIG;
+    const size_t lds = reset_lds_bytes(*cfg);
+    if (lds > 160 * 1024) return PE_ERR_BAD_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t N = st->N, P = cfg->P;
+    hipError_t e;
+#define PE_TRY(x) do { e = (x); if (e != hipSuccess) return (int)e; } while (0)
+    if (lds > 48 * 1024) PE_TRY(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int32_t *d_obs = nullptr;
+    double *d_def = nullptr;
+    PE_TRY(hipMallocAsync((void **)&d_obs, N * cfg->O * 2 * sizeof(int32_t), s));
+    PE_TRY(hipMallocAsync((void **)&d_def, N * P * 4 * sizeof(double), s));
+    DevRng *rng = (DevRng *)reset_state;
+    uint8_t *bank = (uint8_t *)reset_state + N * sizeof(DevRng);
+    hipLaunchKernelGGL(k_reset, dim3(N), dim3(WAVE), lds, s, *cfg, *st, *prm, rng, bank, (int)first, d_obs, d_def, o_state);
+    hipLaunchKernelGGL(k_build_bidx, dim3(N), dim3(256), 0, s, *cfg, *st, (const int32_t *)d_obs);
+    int tot = (int)(N * P * 4);
+    hipLaunchKernelGGL(k_def_aos_to_soa, dim3((tot + 255) / 256), dim3(256), 0, s, (int)N, (int)P, (const double *)d_def, st->def);
+    if (reset_rn) PE_TRY(hipMemsetAsync(st->rn, 0, N * (1 + 2 * P) * sizeof(double), s));
+    PE_TRY(hipFreeAsync(d_obs, s));
+    PE_TRY(hipFreeAsync(d_def, s));
+#undef PE_TRY
+    return (int)hipGetLastError();
 }
 
 int pe_env_load(const pe_config *cfg, const pe_state *st, const pe_host_init *h, void *stream) {

@@ -95,6 +95,10 @@ def load_library():
         L.pe_resetter_state_bytes.restype = C.c_int64
         L.pe_resetter_get_state.argtypes = [vp, vp]
         L.pe_resetter_set_state.argtypes = [vp, vp]
+        L.pe_reset_state_bytes.argtypes = [vp, C.c_int32]
+        L.pe_reset_state_bytes.restype = C.c_int64
+        L.pe_env_reset_seed.argtypes = [vp, C.c_int32, vp, vp, vp]
+        L.pe_env_reset.argtypes = [vp, vp, vp, vp, C.c_int32, vp, C.c_int32, vp]
         L.pe_error_string.argtypes = [C.c_int]
         L.pe_error_string.restype = C.c_char_p
         _lib = L
@@ -331,6 +335,65 @@ def astar_batch(W, H, obs, sg, max_path=256):
     return path.cpu().numpy(), lens.cpu().numpy()
 
 
+def _reset_params(cfg):
+    prm = PeResetParams()
+    prm.num_blocks = int(cfg.map.num_obstacle_block)
+    prm.min_dist = 4  # pursuit_env.py:71
+    prm.center[0], prm.center[1] = float(cfg.map.center[0]), float(cfg.map.center[1])
+    prm.variance = float(cfg.map.variance)
+    return prm
+
+
+def _seed_array(seeds):
+    s = np.ascontiguousarray(seeds, np.uint64)
+    if (s >> np.uint64(32)).any():
+        raise ValueError("seeds must fit 32 bits (numpy.random.seed range)")
+    return s
+
+
+class DeviceResetter:
+    """Pursuit_Env.reset() on the GPU (csrc/pe_env.hip k_reset): the generator streams of every environment live in device
+    memory; same streams, same draws, same results as HostResetter, with no host arrays and no upload."""
+
+    def __init__(self, sim, cfg, seeds):
+        self.L = load_library()
+        self.sim = sim
+        self.c = sim.c
+        self.N = len(seeds)
+        assert self.N == sim.N
+        self.prm = _reset_params(cfg)
+        s = _seed_array(seeds)
+        n = self.L.pe_reset_state_bytes(C.byref(self.c), self.N)
+        self.state = torch.empty(n, dtype=torch.uint8, device=sim.device)
+        with torch.cuda.device(sim.device):
+            _check(self.L.pe_env_reset_seed(C.byref(self.c), self.N, _np(s), _ptr(self.state), _stream()), "pe_env_reset_seed")
+        self.first = True
+
+    def get_state(self):
+        return dict(blob=self.state.cpu().numpy(), first=self.first, device=True)
+
+    def set_state(self, state):
+        buf = np.ascontiguousarray(state["blob"], np.uint8)
+        if not state.get("device") or buf.size != self.state.numel():
+            raise ValueError("resetter state does not match this configuration / number of environments / reset mode")
+        self.state.copy_(torch.from_numpy(buf))
+        self.first = bool(state["first"])
+
+    def reset(self, reset_reward_norm=False):
+        """Next episode of every environment, in place in the simulator state (reads the finished episode's tape position
+        from the device)."""
+        sim = self.sim
+        sim._join()
+        with torch.cuda.device(sim.device):
+            _check(self.L.pe_env_reset(C.byref(self.c), C.byref(sim.st), C.byref(self.prm), _ptr(self.state), 1 if self.first else 0,
+                                       _ptr(sim.o_state), 1 if reset_reward_norm else 0, _stream()), "pe_env_reset")
+        self.first = False
+        sim.t_host = 0
+        worst = int(sim.n_obs.max().item())
+        if worst > self.c.O:
+            raise ValueError(f"an environment has {worst} boundary obstacles > num_max_obstacle={self.c.O}")
+
+
 class HostResetter:
     """Host side of Pursuit_Env.reset() for N environments (csrc/pe_reset.cpp): per-environment re-implementations of
     the reference's `random` / `numpy.random` streams, seeded like random.seed(s); np.random.seed(s)."""
@@ -339,14 +402,8 @@ class HostResetter:
         self.L = load_library()
         self.c = pe_cfg
         self.N = len(seeds)
-        prm = PeResetParams()
-        prm.num_blocks = int(cfg.map.num_obstacle_block)
-        prm.min_dist = 4  # pursuit_env.py:71
-        prm.center[0], prm.center[1] = float(cfg.map.center[0]), float(cfg.map.center[1])
-        prm.variance = float(cfg.map.variance)
-        s = np.ascontiguousarray(seeds, np.uint64)
-        if (s >> np.uint64(32)).any():
-            raise ValueError("seeds must fit 32 bits (numpy.random.seed range)")
+        prm = _reset_params(cfg)
+        s = _seed_array(seeds)
         self.h = self.L.pe_resetter_create(C.byref(pe_cfg), C.byref(prm), self.N, _np(s))
         if not self.h:
             raise RuntimeError("pe_resetter_create failed (bad configuration)")

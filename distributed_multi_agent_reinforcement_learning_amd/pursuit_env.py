@@ -34,7 +34,10 @@ class Pursuit_Env:
             base = int(rt.get("seed", 0)) + max(1000, self.num_envs) * int(rank)  # disjoint streams per rank (1000 * rank below 1000 envs)
             seeds = [base + n for n in range(self.num_envs)]
         self.seeds = list(seeds)
-        self.resetter = pe_env.HostResetter(self.pe_cfg, cfg, self.seeds)
+        # runtime.device_reset: the episode reset runs on the GPU (same streams and draws as the host resetter, no upload)
+        self.device_reset = bool(rt.get("device_reset", False))
+        self.resetter = (pe_env.DeviceResetter(self.sim, cfg, self.seeds) if self.device_reset
+                         else pe_env.HostResetter(self.pe_cfg, cfg, self.seeds))
         self.boundary_map = SimpleNamespace(obstacle_agent=self.sim.o_state)  # (N, O, 4) [x, y, 0, 0], zero padded
         self._obs = None
         self._reward = torch.zeros((self.num_envs, self.num_defender), dtype=torch.float32, device=self.device)
@@ -46,6 +49,10 @@ class Pursuit_Env:
         """pursuit_env.py:60-73.  `init` (host arrays, see BatchedEnv.load) injects recorded initial conditions."""
         self.time_step = 0
         self.n_episode += 1
+        if init is None and self.device_reset:
+            self.resetter.reset()
+            self.last_init = None
+            return None
         if init is None:
             init = self._take_prefetched()
             if init is None:
@@ -60,7 +67,7 @@ class Pursuit_Env:
         """Starts the host-side reset of the next episode in a background thread (the C++ resetter releases the GIL).  Call
         it once the running episode is over: the number of tape targets it consumed is read here."""
         import threading
-        if getattr(self, "_prefetch", None) is not None:
+        if self.device_reset or getattr(self, "_prefetch", None) is not None:
             return
         self.check_status()
         consumed = None if self.resetter.first else self.sim.meta[:, pe_env.META_TAPE_POS].cpu().numpy()

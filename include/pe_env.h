@@ -133,6 +133,20 @@ int64_t pe_resetter_state_bytes(void *resetter);
 int pe_resetter_get_state(void *resetter, void *out);
 int pe_resetter_set_state(void *resetter, const void *in);
 
+/* Pursuit_Env.reset() on the DEVICE (pursuit_env.py:60-73, base_env.py:37-162, Occupied_Grid_Map.py:46-62,
+ * 119-166): the same streams and draws as the host resetter above, one wavefront per environment, no host arrays and no
+ * upload.  reset_state: device memory of pe_reset_state_bytes(cfg, N) bytes that holds every environment's two
+ * generator states and the inflated map of its running episode between calls (opaque; copy it to save / restore).
+ *   pe_env_reset_seed: random.seed(seeds[n]); np.random.seed(seeds[n]) for every environment (seeds: HOST array).
+ *   pe_env_reset: next episode.  first != 0 on the first reset after seeding; afterwards the number of tape targets the
+ *   finished episode consumed is read from state->meta and the unused draws go back to the stream.  o_state (may be
+ *   NULL): [N][O][4] fp32 rows [x, y, 0, 0] of the boundary obstacles, zero padded (boundary_map.obstacle_agent).
+ *   state->n_obs[n] may exceed cfg->O (the caller must check, as pe_env_load's caller does). */
+int64_t pe_reset_state_bytes(const pe_config *cfg, int32_t N);
+int pe_env_reset_seed(const pe_config *cfg, int32_t N, const uint64_t *seeds, void *reset_state, void *stream);
+int pe_env_reset(const pe_config *cfg, const pe_state *st, const pe_reset_params *prm, void *reset_state, int32_t first, float *o_state,
+                 int32_t reset_rn, void *stream);
+
 /* Validates a configuration against the kernels' limits. */
 int pe_config_check(const pe_config *cfg);
 /* Bytes of dynamic LDS one workgroup of the fused tick uses (for occupancy reports). */

@@ -207,3 +207,48 @@ def test_reference_default_geometry_matches_oracle():
             oe.reward_norm(r)
             assert np.array_equal(r_raw[n], r.astype(np.float32)) and np.array_equal(defs[n], oe.state()["defenders"]), (t, n)
     assert not env.status().any().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,num_envs", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 4096)])
+def test_device_reset_equals_host_reset(name, num_envs):
+    """On-device Pursuit_Env.reset (k_reset) == the host resetter bit for bit: maps, boundary obstacle order, targets,
+    defender / evader positions (f64), target tapes, over three episodes with real tape consumption in between (the
+    unused tape draws must go back to the stream the same way).  The host resetter itself is pinned to the reference's
+    reset by tests/test_reset_host.py."""
+    from distributed_multi_agent_reinforcement_learning_amd.config import baseline_config
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from distributed_multi_agent_reinforcement_learning_amd import pe_env
+    cfg_h = baseline_config(name, **{"runtime.num_envs": num_envs, "runtime.device_reset": False})
+    cfg_d = baseline_config(name, **{"runtime.num_envs": num_envs, "runtime.device_reset": True})
+    eh, ed = Pursuit_Env(cfg_h), Pursuit_Env(cfg_d)
+    assert isinstance(ed.resetter, pe_env.DeviceResetter) and isinstance(eh.resetter, pe_env.HostResetter)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    P = cfg_h.env.num_defender
+    for episode in range(3):
+        eh.reset(); ed.reset()
+        sh, sd = eh.sim, ed.sim
+        for key in ("grid", "bidx", "n_obs", "target", "tape", "eva", "wpw"):
+            assert torch.equal(getattr(sh, key), getattr(sd, key)), (episode, key)
+        assert torch.equal(sh.defenders_aos(), sd.defenders_aos()), episode
+        assert torch.equal(sh.o_state, sd.o_state), episode
+        assert torch.equal(sh.meta, sd.meta), episode
+        # a stretch of the episode so that evaders reach targets and consume tape entries (different counts per environment)
+        oh, od = sh.new_obs(), sd.new_obs()
+        rh = torch.zeros(num_envs, P, device="cuda"); rd = torch.zeros_like(rh)
+        eh.observe(oh); eh.attacker_step(); ed.observe(od); ed.attacker_step()
+        for t in range(60):
+            a = torch.randint(0, 9, (num_envs, P), generator=g, device="cuda", dtype=torch.int32)
+            eh.tick(a, oh, rh); ed.tick(a, od, rd)
+        torch.cuda.synchronize()
+        assert torch.equal(sh.meta, sd.meta) and torch.equal(sh.eva, sd.eva)
+        if episode == 0:
+            assert int(sh.meta[:, pe_env.META_TAPE_POS].max().item()) > 0   # the rewind path is exercised
+    # the resume snapshot of the device streams round-trips
+    snap, meta = ed.resetter.get_state(), ed.sim.meta.clone()   # + the finished episode's tape position (Trainer.save_resume)
+    ed.reset()
+    ref = (ed.sim.grid.clone(), ed.sim.eva.clone(), ed.sim.tape.clone())
+    ed.resetter.set_state(snap)
+    ed.sim.meta.copy_(meta)
+    ed.reset()
+    assert all(torch.equal(a, b) for a, b in zip(ref, (ed.sim.grid, ed.sim.eva, ed.sim.tape)))

@@ -13,3 +13,20 @@ for th in (1, 2, 4, 8, 16):
     cons = np.zeros(4096, np.int32)
     r.reset(cons); t2 = time.perf_counter()
     print(f"threads {th:2d}: first reset {1e3*(t1-t0):7.1f} ms, next reset {1e3*(t2-t1):7.1f} ms")
+
+try:
+    import torch
+    if torch.cuda.is_available():
+        from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+        for name in ("cfg2",):
+            env = Pursuit_Env(baseline_config(name, **{"runtime.device_reset": True}), num_envs=4096)
+            env.reset(); torch.cuda.synchronize()
+            for rep in range(3):
+                t0 = time.perf_counter(); env.reset(); torch.cuda.synchronize()
+                print(f"device reset of 4096 envs ({name}): {1e3*(time.perf_counter()-t0):.2f} ms")
+            envh = Pursuit_Env(baseline_config(name), num_envs=4096)
+            envh.reset(); torch.cuda.synchronize()
+            t0 = time.perf_counter(); envh.reset(); torch.cuda.synchronize()
+            print(f"host reset + upload of 4096 envs ({name}): {1e3*(time.perf_counter()-t0):.2f} ms")
+except ImportError:
+    pass
