@@ -73,9 +73,14 @@ class DHGN(nn.Module):
         emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)                       # one GEMM (+relu epilogue) for the three relations
         # semantic_layer([p, emb0, emb1, emb2]) without materialising the concatenation (:284-303)
         Ws = self.semantic_layer.weight
-        # the position part (K = 4) first, the embedding part accumulates onto it in its GEMM epilogue (beta = 1)
-        small = F.linear(p.reshape(R * P, ind), Ws[:, :ind], self.semantic_layer.bias)
-        h0 = ops.linear(emb.reshape(R * P, 3 * E), Ws[:, ind:], small, out=None if out is None else out.view(R * P, E))
+        # the position part (K = 4) first, the embedding part accumulates INTO it (beta = 1, no copy of the addend)
+        p2, e2 = p.reshape(R * P, ind), emb.reshape(R * P, 3 * E)
+        if out is not None:  # rollout: both GEMMs write the static storage
+            o2 = out.view(R * P, E)
+            torch.addmm(self.semantic_layer.bias, p2, Ws[:, :ind].t(), out=o2)
+            h0 = o2.addmm_(e2, Ws[:, ind:].t())
+        else:
+            h0 = ops.linear(e2, Ws[:, ind:], F.linear(p2, Ws[:, :ind], self.semantic_layer.bias), consume_addend=True)
         return h0.reshape(R, P, E)
 
     # -- fixed-depth recursive aggregation over neighbours' historical embeddings (:204-233) --------------
@@ -91,8 +96,9 @@ class DHGN(nn.Module):
             aggk = self.AGG_layers[f"AGG_fcra_{k}"]
             agg = ops.linear(torch.matmul(abar, hist[k]), aggk.weight, aggk.bias, relu=True)
             Wf = self.FCRA_layers[k].weight  # FCRA_k([agg, h]) as two accumulating GEMMs instead of a concatenation
+            last = out is not None and k == self.depth - 1
             h = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias), relu=True,
-                           out=out if k == self.depth - 1 else None)
+                           out=out if last else None, consume_addend=not last)
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):

@@ -273,31 +273,46 @@ def wgrad(a, b, out=None, accumulate=False):
     return out
 
 
-def _linear_fwd(x, W, b, out=None, relu=False):
+def _linear_fwd(x, W, b, out=None, relu=False, consume_addend=False):
     """x W^T + b; b is a bias (out,) or a full addend of the output's shape (the add rides in the GEMM epilogue, beta = 1);
-    relu with a 1-D bias rides in the hipBLASLt epilogue as well (bit-identical to relu(linear))."""
+    relu with a 1-D bias rides in the hipBLASLt epilogue as well (bit-identical to relu(linear)).
+    consume_addend: the full addend b is a temporary the caller no longer needs -- the product accumulates INTO it
+    (no copy of b into a fresh result, no extra relu output); the returned tensor is b itself."""
+    x2 = x.reshape(-1, W.shape[1])
+    oshape = x.shape[:-1] + (W.shape[0],)
+    if consume_addend and b is not None and b.dim() > 1 and out is None and b.is_contiguous():
+        y = b.view(-1, W.shape[0]).addmm_(x2, W.t())
+        if relu:
+            y.clamp_min_(0.0)
+        return b
     if relu:
         if b is not None and b.dim() == 1 and out is None:
-            y = torch._addmm_activation(b, x.reshape(-1, W.shape[1]), W.t(), use_gelu=False)
-            return y.reshape(x.shape[:-1] + (W.shape[0],))
+            return torch._addmm_activation(b, x2, W.t(), use_gelu=False).reshape(oshape)
         y = _linear_fwd(x, W, b)
         return torch.clamp_min(y, 0.0, out=out.view(y.shape) if out is not None else None)
+    res = None
+    if out is None:  # the result is allocated in its final shape: a base tensor, not a view (it may be consumed in place later)
+        res = torch.empty(oshape, dtype=x.dtype, device=x.device)
+        out = res.view(-1, W.shape[0])
     if b is None:
-        y = torch.mm(x.reshape(-1, W.shape[1]), W.t(), out=out)
+        y = torch.mm(x2, W.t(), out=out)
     else:
-        y = torch.addmm(b if b.dim() == 1 else b.reshape(-1, W.shape[0]), x.reshape(-1, W.shape[1]), W.t(), out=out)
-    return y.reshape(x.shape[:-1] + (W.shape[0],))
+        y = torch.addmm(b if b.dim() == 1 else b.reshape(-1, W.shape[0]), x2, W.t(), out=out)
+    return res if res is not None else y.reshape(oshape)
 
 
 class _Linear(torch.autograd.Function):
     """x W^T + b whose weight gradient runs in the split-K MFMA kernel (wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu):
+    def forward(ctx, x, W, b, relu, consume_addend):
         ctx.bias_kind = 0 if b is None else (1 if b.dim() == 1 else 2)
         ctx.b_shape = None if b is None else b.shape
         ctx.relu = relu
-        y = _linear_fwd(x, W, b, None, relu)
+        inplace = bool(consume_addend and ctx.bias_kind == 2 and b.is_contiguous() and b.shape == x.shape[:-1] + (W.shape[0],))
+        if inplace:
+            ctx.mark_dirty(b)
+        y = _linear_fwd(x, W, b, None, relu, inplace)
         ctx.save_for_backward(x, W, y if relu else None)
         return y
 
@@ -313,16 +328,17 @@ class _Linear(torch.autograd.Function):
         db = None
         if ctx.bias_kind and ctx.needs_input_grad[2]:
             db = g2.sum(0) if ctx.bias_kind == 1 else g.reshape(ctx.b_shape)
-        return dx, dW, db, None
+        return dx, dW, db, None, None
 
 
-def linear(x, W, b=None, out=None, relu=False):
+def linear(x, W, b=None, out=None, relu=False, consume_addend=False):
     """F.linear(x, W, b), optionally followed by relu (W may be a column slice of a larger weight; b a bias or a full
-    addend); under autograd the weight gradient uses wgrad.  out (no autograd): written in place."""
+    addend); under autograd the weight gradient uses wgrad.  out (no autograd): written in place.  consume_addend: see
+    _linear_fwd (b must be a temporary: it becomes the result)."""
     if torch.is_grad_enabled() and (W.requires_grad or x.requires_grad or (b is not None and b.requires_grad)):
         assert out is None
-        return _Linear.apply(x, W, b, relu)
-    return _linear_fwd(x, W, b, out, relu)
+        return _Linear.apply(x, W, b, relu, consume_addend)
+    return _linear_fwd(x, W, b, out, relu, consume_addend)
 
 
 FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel
