@@ -271,7 +271,7 @@ def main():
                                    f"DHGN depth {cfg.algo.depth} + 2-layer GRU actor/critic, rollout + PPO update",
                        "envs_per_gpu": N, "episode_steps": T, "mini_batch_size": tr.mini_batch_size, "parallelism": f"dp{world}"},
             "ppo_updates_per_s": round(args.steps * cfg.algo.epochs / dt, 4),
-            "breakdown_ms": {"rollout_incl_host_reset": round(rollout_ms, 1), "gae_ppo_update_allreduce_adam": round(update_ms, 1)},
+            "breakdown_ms": {"rollout_incl_reset": round(rollout_ms, 1), "gae_ppo_update_allreduce_adam": round(update_ms, 1)},
             "roofline": roofline,
             "roofline_compute_kernels": extra,
         }
