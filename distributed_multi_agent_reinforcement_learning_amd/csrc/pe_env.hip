@@ -16,6 +16,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <cmath>
+
 #include "pe_env.h"
 
 namespace {
@@ -27,6 +29,18 @@ constexpr double SQRT2 = 0x1.6a09e667f3bcdp+0;  // math.hypot(1, 1)  (astar.py:9
 
 __device__ __forceinline__ int py_round(double v) { return (int)__builtin_rint(v); }
 __device__ __forceinline__ double norm2(double a, double b) { return __builtin_sqrt(__builtin_fma(b, b, a * a)); }
+// norm2(a, b) <= r without the f64 square root on the device: sqrt is correctly rounded and monotone, so
+// { x : sqrt(x) <= r } = { x : x <= t } for the largest double t with sqrt(t) <= r (likewise for <).  The thresholds of
+// the configuration's radii are found on the host (launch()) with the same correctly rounded sqrt; a comparison of
+// the squared norm against them decides exactly like the reference's comparison of the norm.
+__device__ __forceinline__ double norm2sq(double a, double b) { return __builtin_fma(b, b, a * a); }
+struct SqThr {
+    double coll_le;     // sqrt(x) <= defender.collision_radius
+    double comm_le;     // sqrt(x) <= defender.comm_range
+    double sen_le;      // sqrt(x) <= defender.sen_range
+    double evacoll_le;  // sqrt(x) <= attacker.collision_radius
+    double res_lt;      // sqrt(x) <  map.resolution
+};
 
 // One wave per workgroup: the lanes only ever exchange data with lanes of their own wave.  A wave's LDS and vector-memory
 // instructions execute in program order through the same LDS / L1, so a wavefront-scope fence (no s_waitcnt, no s_barrier)
@@ -199,7 +213,7 @@ __device__ __forceinline__ void dynamic(double tau, double h, double x, double y
 __device__ __forceinline__ bool in_bound_i(const pe_config &c, int x, int y) { return x < c.W && x >= 0 && y < c.H && y >= 0; }
 
 // ---- defenders: Pursuit_Env.step + defender_reward + collision_detection (pursuit_env.py:104-177) ------
-__device__ void dev_step(const pe_config &c, const Lds &l, int lane, double *def_hbm, const pe_step_out &out, int env) {
+__device__ void dev_step(const pe_config &c, const SqThr &th, const Lds &l, int lane, double *def_hbm, const pe_step_out &out, int env) {
     const int P = c.P;
     int32_t *meta = l.m;
     double *rn = l.rnl;
@@ -218,7 +232,7 @@ __device__ void dev_step(const pe_config &c, const Lds &l, int lane, double *def
     for (int i = 0; i < P; i++) {  // sequential in the agent index: proposals are clipped in place
         const double sx = l.prop[i], sy = l.prop[P + i];
         // inner collisions against the current (possibly already clipped) proposals, self included
-        bool near = (lane < P) && (norm2(l.prop[lane] - sx, l.prop[P + lane] - sy) <= r);
+        bool near = (lane < P) && (norm2sq(l.prop[lane] - sx, l.prop[P + lane] - sy) <= th.coll_le);
         int cnt = __popcll(__ballot(near));
         // 3x3 probe of the static map at half-radius offsets; only in-bound probes count (pursuit_env.py:152-163)
         bool hit = false;
@@ -237,7 +251,7 @@ __device__ void dev_step(const pe_config &c, const Lds &l, int lane, double *def
             double cx = sx < 0.0 ? 0.0 : (sx > (double)(c.W - 1) ? (double)(c.W - 1) : sx);
             double cy = sy < 0.0 ? 0.0 : (sy > (double)(c.H - 1) ? (double)(c.H - 1) : sy);
             if (lane == 0) { l.prop[i] = cx; l.prop[P + i] = cy; }
-            if (norm2(ex - cx, ey - cy) <= r) rew += 1;
+            if (norm2sq(ex - cx, ey - cy) <= th.coll_le) rew += 1;
             ok = 1;
         }
         if (lane == i) { my_rew = rew; my_ok = ok; }
@@ -280,7 +294,7 @@ __device__ void dev_step(const pe_config &c, const Lds &l, int lane, double *def
 }
 
 // ---- observations: get_state, communicate, sensor (base_env.py:198-209, pursuit_env.py:182-209) --------
-__device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env, const pe_obs_out &o, int n_obs, uint32_t *lcache_hbm) {
+__device__ void dev_observe(const pe_config &c, const SqThr &th, const Lds &l, int lane, int env, const pe_obs_out &o, int n_obs, uint32_t *lcache_hbm) {
     uint32_t *lcache = l.lc;
     const int P = c.P, O = c.O;
     if (o.p_state && lane < 4 * P) o.p_state[(int64_t)env * o.p_state_stride + lane] = (float)l.def[(lane & 3) * P + (lane >> 2)];
@@ -288,7 +302,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
     // communicate(): upper-triangular range test plus the adj[j, 1] = 1 side effect
     for (int idx = lane; idx < P * P; idx += WAVE) {
         int i = idx / P, j = idx - i * P;
-        l.cond[idx] = (i <= j) && (norm2(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= c.def_comm_range);
+        l.cond[idx] = (i <= j) && (norm2sq(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= th.comm_le);
     }
     for (int idx = lane; idx < (P * O) >> 2; idx += WAVE) ((uint32_t *)l.oadj)[idx] = 0u;  // O is a multiple of 4
     wave_sync();
@@ -307,7 +321,7 @@ __device__ void dev_observe(const pe_config &c, const Lds &l, int lane, int env,
         int x0 = py_round(l.def[lane]), y0 = py_round(l.def[P + lane]);
         int x1 = py_round(l.eva[0]), y1 = py_round(l.eva[1]);
         float seen = 0.f;
-        if (!(norm2((double)(x0 - x1), (double)(y0 - y1)) > c.def_sen_range)) {
+        if (norm2sq((double)(x0 - x1), (double)(y0 - y1)) <= th.sen_le) {
             int dx = abs(x1 - x0), dy = abs(y1 - y0);
             int sx = x0 > x1 ? -1 : 1, sy = y0 > y1 ? -1 : 1;
             int err = dx - dy;
@@ -616,7 +630,7 @@ __device__ __forceinline__ uint32_t dev_waypoint(const Lds &l, const int16_t *pa
 
 // ---- Pursuit_Env.attacker_step (pursuit_env.py:75-102), waypoint2phi (agent.py:261-271) -----------------
 template <bool REPLAN>
-__device__ void dev_evader(const pe_config &c, const Lds &l, int lane, int16_t *path, uint32_t *wp_hbm, int32_t *target_hbm,
+__device__ void dev_evader(const pe_config &c, const SqThr &th, const Lds &l, int lane, int16_t *path, uint32_t *wp_hbm, int32_t *target_hbm,
                            const int32_t *tape_hbm, double *eva_hbm) {
     int32_t *meta = l.m;
     const int t = meta[PE_META_T];
@@ -633,7 +647,7 @@ __device__ void dev_evader(const pe_config &c, const Lds &l, int lane, int16_t *
         // path[cnt-1] is the next waypoint; the window holds it without a dependent global read
         uint32_t wv = dev_waypoint(l, path, head, cnt);
         double wx = (double)(int16_t)(wv >> 16), wy = (double)(int16_t)(wv & 0xFFFFu);
-        if (len >= 2 && norm2(ex - wx, ey - wy) < c.resolution) {
+        if (len >= 2 && norm2sq(ex - wx, ey - wy) <= th.res_lt) {
             len--;
             if (cnt > 1) {
                 cnt--; head++;
@@ -661,7 +675,7 @@ __device__ void dev_evader(const pe_config &c, const Lds &l, int lane, int16_t *
             eva_hbm[0] = ns[0]; eva_hbm[1] = ns[1]; eva_hbm[2] = ns[2]; eva_hbm[3] = ns[3];
         }
         // the target is re-drawn when the PROPOSED position reaches it (pursuit_env.py:98-100); draws come from the tape
-        if (norm2((double)l.tg()[0] - ns[0], (double)l.tg()[1] - ns[1]) <= c.eva_collision_radius) {
+        if (norm2sq((double)l.tg()[0] - ns[0], (double)l.tg()[1] - ns[1]) <= th.evacoll_le) {
             int pos = meta[PE_META_TAPE_POS];
             int k = pos < c.tape_len ? pos : c.tape_len - 1;
             if (pos >= c.tape_len) status |= PE_STATUS_TAPE_EXHAUSTED;
@@ -681,7 +695,7 @@ __device__ void dev_evader(const pe_config &c, const Lds &l, int lane, int16_t *
 
 template <bool STEP, bool OBS, bool EVA, bool REPLAN>
 __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state st, const int32_t *actions, const pe_step_out sout,
-                                               const pe_obs_out oout) {
+                                               const pe_obs_out oout, const SqThr th) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int env = blockIdx.x, lane = threadIdx.x;
     if (env >= st.N) return;
@@ -747,9 +761,9 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
     if (EVA && lane < PE_WP_WINDOW) l.wp()[lane] = r_wp;
     if (EVA && lane < 2 * c.tape_len && lane < 2 * PE_TAPE_LDS) l.tp()[lane] = r_tp;
     wave_sync();
-    if (STEP) dev_step(c, l, lane, def_hbm, sout, env);
-    if (OBS) dev_observe(c, l, lane, env, oout, r_nobs, lc_hbm);
-    if (EVA) dev_evader<REPLAN>(c, l, lane, st.path + (size_t)env * c.max_path * 2, wp_hbm, target_hbm, tape_hbm, eva_hbm);
+    if (STEP) dev_step(c, th, l, lane, def_hbm, sout, env);
+    if (OBS) dev_observe(c, th, l, lane, env, oout, r_nobs, lc_hbm);
+    if (EVA) dev_evader<REPLAN>(c, th, l, lane, st.path + (size_t)env * c.max_path * 2, wp_hbm, target_hbm, tape_hbm, eva_hbm);
     // ---- write the small records back (def / eva / target / LiDAR cache were written where they changed)
     if ((STEP || EVA) && lane < PE_META_INTS) meta_hbm[lane] = l.m[lane];
     if (STEP && c.use_reward_norm && lane < 1 + 2 * P) rn_hbm[lane] = l.rnl[lane];
@@ -807,6 +821,21 @@ __global__ void k_diag_norm2(int n, const double *a, const double *b, double *ou
     }
 }
 
+// Host: the largest double t with sqrt(t) <= r (strict: sqrt(t) < r); -1 when no x >= 0 qualifies (a squared norm is >= 0).
+double sq_threshold(double r, bool strict) {
+    auto ok = [&](double t) { const double s = sqrt(t); return strict ? s < r : s <= r; };
+    if (!(r >= 0.0) || !ok(0.0)) return -1.0;
+    if (std::isinf(r)) return r;
+    double t = r * r;
+    while (!ok(t)) t = nextafter(t, 0.0);
+    for (;;) {
+        const double n = nextafter(t, INFINITY);
+        if (std::isinf(n) || !ok(n)) break;
+        t = n;
+    }
+    return t;
+}
+
 template <bool STEP, bool OBS, bool EVA, bool REPLAN>
 int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
     size_t lds = lds_layout(*cfg, OBS, EVA && REPLAN, nullptr, nullptr);
@@ -819,7 +848,13 @@ int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, con
     memset(&s0, 0, sizeof s0);
     pe_obs_out o0;
     memset(&o0, 0, sizeof o0);
-    hipLaunchKernelGGL(kern, dim3(st->N), dim3(WAVE), lds, (hipStream_t)stream, *cfg, *st, actions, so ? *so : s0, oo ? *oo : o0);
+    SqThr th;
+    th.coll_le = sq_threshold(cfg->def_collision_radius, false);
+    th.comm_le = sq_threshold(cfg->def_comm_range, false);
+    th.sen_le = sq_threshold(cfg->def_sen_range, false);
+    th.evacoll_le = sq_threshold(cfg->eva_collision_radius, false);
+    th.res_lt = sq_threshold(cfg->resolution, true);
+    hipLaunchKernelGGL(kern, dim3(st->N), dim3(WAVE), lds, (hipStream_t)stream, *cfg, *st, actions, so ? *so : s0, oo ? *oo : o0, th);
     return (int)hipGetLastError();
 }
 
