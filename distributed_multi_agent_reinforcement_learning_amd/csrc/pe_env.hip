@@ -34,7 +34,18 @@ __device__ __forceinline__ double norm2(double a, double b) { return __builtin_s
 // the configuration's radii are found on the host (launch()) with the same correctly rounded sqrt; a comparison of
 // the squared norm against them decides exactly like the reference's comparison of the norm.
 __device__ __forceinline__ double norm2sq(double a, double b) { return __builtin_fma(b, b, a * a); }
+// a / b for a divisor known on the host, in three flops instead of the ~15-instruction IEEE sequence: with y = RN(1 / b),
+// q = RN(a y), r = a - b q (exact in one fma) the corrected q' = RN(q + r y) is the correctly rounded quotient
+// (Markstein) unless b's significand is all ones -- the host checks that and the exponent range and then passes y = 0,
+// which selects the plain division.  r == 0 keeps q (also keeps the sign of a zero quotient).
+__device__ __forceinline__ double div_const(double a, double b, double y) {
+    if (y == 0.0) return a / b;  // wave-uniform
+    const double q = a * y;
+    const double r = __builtin_fma(-q, b, a);
+    return r == 0.0 ? q : __builtin_fma(r, y, q);
+}
 struct SqThr {
+    double inv_def_tau, inv_eva_tau, inv_six;  // RN(1 / b) for div_const, 0 = use the IEEE division
     double coll_le;     // sqrt(x) <= defender.collision_radius
     double comm_le;     // sqrt(x) <= defender.comm_range
     double sen_le;      // sqrt(x) <= defender.sen_range
@@ -192,18 +203,18 @@ __device__ __forceinline__ void copy_out_f32(float *dst, const float *src, int n
 }
 
 // ---- agent.py:74-104 : first-order lag integrated with RK4, association exactly as written -------------
-__device__ __forceinline__ void dynamic(double tau, double h, double x, double y, double vx0, double vy0, double ux, double uy,
-                                        double *o) {
-    double k1 = (ux - vx0) / tau;
-    double k2 = (ux - (vx0 + h * k1 / 2)) / tau;
-    double k3 = (ux - (vx0 + h * k2 / 2)) / tau;
-    double k4 = (ux - (vx0 + h * k3)) / tau;
-    double vx = vx0 + (k1 + 2 * k2 + 2 * k3 + k4) * h / 6;
-    k1 = (uy - vy0) / tau;
-    k2 = (uy - (vy0 + h * k1 / 2)) / tau;
-    k3 = (uy - (vy0 + h * k2 / 2)) / tau;
-    k4 = (uy - (vy0 + h * k3)) / tau;
-    double vy = vy0 + (k1 + 2 * k2 + 2 * k3 + k4) * h / 6;
+__device__ __forceinline__ void dynamic(double tau, double itau, double i6, double h, double x, double y, double vx0, double vy0, double ux,
+                                        double uy, double *o) {
+    double k1 = div_const(ux - vx0, tau, itau);
+    double k2 = div_const(ux - (vx0 + h * k1 / 2), tau, itau);
+    double k3 = div_const(ux - (vx0 + h * k2 / 2), tau, itau);
+    double k4 = div_const(ux - (vx0 + h * k3), tau, itau);
+    double vx = vx0 + div_const((k1 + 2 * k2 + 2 * k3 + k4) * h, 6.0, i6);
+    k1 = div_const(uy - vy0, tau, itau);
+    k2 = div_const(uy - (vy0 + h * k1 / 2), tau, itau);
+    k3 = div_const(uy - (vy0 + h * k2 / 2), tau, itau);
+    k4 = div_const(uy - (vy0 + h * k3), tau, itau);
+    double vy = vy0 + div_const((k1 + 2 * k2 + 2 * k3 + k4) * h, 6.0, i6);
     o[0] = x + vx * h;
     o[1] = y + vy * h;
     o[2] = vx;
@@ -221,7 +232,7 @@ __device__ void dev_step(const pe_config &c, const SqThr &th, const Lds &l, int 
         int a = l.acts()[lane];
         a = a < 0 ? 0 : (a > 8 ? 8 : a);
         double o[4];
-        dynamic(c.def_tau, c.def_dt, l.def[lane], l.def[P + lane], l.def[2 * P + lane], l.def[3 * P + lane], c.action_u[a][0],
+        dynamic(c.def_tau, th.inv_def_tau, th.inv_six, c.def_dt, l.def[lane], l.def[P + lane], l.def[2 * P + lane], l.def[3 * P + lane], c.action_u[a][0],
                 c.action_u[a][1], o);
         l.prop[lane] = o[0]; l.prop[P + lane] = o[1]; l.prop[2 * P + lane] = o[2]; l.prop[3 * P + lane] = o[3];
     }
@@ -668,7 +679,7 @@ __device__ void dev_evader(const pe_config &c, const SqThr &th, const Lds &l, in
             sphi = dy > 0.0 ? s : -s;
         }
         double ns[4];
-        dynamic(c.eva_tau, c.eva_dt, ex, ey, l.eva[2], l.eva[3], cphi * c.eva_vmax, sphi * c.eva_vmax, ns);
+        dynamic(c.eva_tau, th.inv_eva_tau, th.inv_six, c.eva_dt, ex, ey, l.eva[2], l.eva[3], cphi * c.eva_vmax, sphi * c.eva_vmax, ns);
         int ix = py_round(ns[0]), iy = py_round(ns[1]);
         if (in_bound_i(c, ix, iy) && l.grid[ix * c.H + iy] == 0) {
             l.eva[0] = ns[0]; l.eva[1] = ns[1]; l.eva[2] = ns[2]; l.eva[3] = ns[3];
@@ -812,12 +823,14 @@ __global__ __launch_bounds__(WAVE) void k_astar(int W, int H, int n, const uint8
     if (lane == 0) { out_len[2 * b] = len; out_len[2 * b + 1] = nexp; }
 }
 
-__global__ void k_diag_norm2(int n, const double *a, const double *b, double *out) {
+__global__ void k_diag_norm2(int n, const double *a, const double *b, double *out, double c0, double y0, double c1, double y1) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         out[i] = norm2(a[i], b[i]);
         out[n + i] = a[i] / b[i];
         out[2 * n + i] = (double)py_round(a[i]);
+        out[3 * n + i] = div_const(a[i], c0, y0);   // vs a / c0 on the host
+        out[4 * n + i] = div_const(b[i], c1, y1);   // vs b / c1
     }
 }
 
@@ -836,6 +849,15 @@ double sq_threshold(double r, bool strict) {
     return t;
 }
 
+// Host: y = RN(1 / b) if div_const is exact for every finite a in the simulator's range, else 0 (plain division).
+double div_const_reciprocal(double b) {
+    if (!(b > 0.0) || std::isinf(b)) return 0.0;
+    int e;
+    const double m = frexp(b, &e);                               // b = m 2^e, m in [0.5, 1)
+    if (m == nextafter(1.0, 0.0) || e < -500 || e > 500) return 0.0;  // significand all ones / far exponents
+    return 1.0 / b;
+}
+
 template <bool STEP, bool OBS, bool EVA, bool REPLAN>
 int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
     size_t lds = lds_layout(*cfg, OBS, EVA && REPLAN, nullptr, nullptr);
@@ -849,6 +871,9 @@ int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, con
     pe_obs_out o0;
     memset(&o0, 0, sizeof o0);
     SqThr th;
+    th.inv_def_tau = div_const_reciprocal(cfg->def_tau);
+    th.inv_eva_tau = div_const_reciprocal(cfg->eva_tau);
+    th.inv_six = div_const_reciprocal(6.0);
     th.coll_le = sq_threshold(cfg->def_collision_radius, false);
     th.comm_le = sq_threshold(cfg->def_comm_range, false);
     th.sen_le = sq_threshold(cfg->def_sen_range, false);
@@ -1270,9 +1295,10 @@ int pe_astar_batch(int32_t W, int32_t H, int32_t n, const uint8_t *obs, const in
     return (int)hipGetLastError();
 }
 
-// diagnostic: device f64 norm / divide / round against the host (tests only)
-int pe_diag_norm2(int32_t n, const double *a, const double *b, double *out, void *stream) {
-    hipLaunchKernelGGL(k_diag_norm2, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, a, b, out);
+// diagnostic: device f64 norm / divide / round / constant-divisor divide (out [5][n]) against the host (tests only)
+int pe_diag_norm2(int32_t n, const double *a, const double *b, double *out, double c0, double c1, void *stream) {
+    hipLaunchKernelGGL(k_diag_norm2, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, a, b, out, c0, div_const_reciprocal(c0), c1,
+                       div_const_reciprocal(c1));
     return (int)hipGetLastError();
 }
 

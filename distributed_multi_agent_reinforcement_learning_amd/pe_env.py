@@ -86,7 +86,7 @@ def load_library():
         L.pe_env_tick.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
         L.pe_env_step_observe.argtypes = [vp, vp, vp, vp, vp, vp]
         L.pe_astar_batch.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]
-        L.pe_diag_norm2.argtypes = [C.c_int32, vp, vp, vp, vp]
+        L.pe_diag_norm2.argtypes = [C.c_int32, vp, vp, vp, C.c_double, C.c_double, vp]
         L.pe_resetter_create.argtypes = [vp, vp, C.c_int32, vp]
         L.pe_resetter_create.restype = vp
         L.pe_resetter_destroy.argtypes = [vp]

@@ -16,7 +16,8 @@ def _env(cfg, N):
 
 
 def test_device_f64_primitives_match_host():
-    """norm2 = sqrt(fma(b,b,a*a)), IEEE divide and round-half-even are bit-identical on gfx950 and the host."""
+    """norm2 = sqrt(fma(b,b,a*a)), IEEE divide, round-half-even and the three-flop division by a host-known constant
+    (div_const: tau = 0.2, 6, and divisors whose reciprocal is inexact in awkward ways) are bit-identical on gfx950 and the host."""
     from distributed_multi_agent_reinforcement_learning_amd import pe_env
     from oracle import pe_oracle
     rng = np.random.default_rng(0)
@@ -24,16 +25,20 @@ def test_device_f64_primitives_match_host():
     a = rng.normal(size=n) * rng.uniform(1e-3, 60, n)
     b = rng.normal(size=n) * rng.uniform(1e-3, 60, n)
     a[:2048] = np.round(a[:2048] * 2) / 2  # exact .5 ties for the rounding test
+    a[2048:2056] = [0.0, -0.0, 5e-324, -5e-324, 1e-310, 1e9, -1e9, 0.2]
     ref = pe_oracle.prims(a, b)
     L = pe_env.load_library()
     ad, bd = torch.as_tensor(a).cuda(), torch.as_tensor(b).cuda()
-    out = torch.zeros((3, n), dtype=torch.float64, device="cuda")
-    rc = L.pe_diag_norm2(n, C.c_void_p(ad.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(out.data_ptr()), None)
-    assert rc == 0
-    torch.cuda.synchronize()
-    got = out.cpu().numpy()
-    for k, name in enumerate(("norm2", "divide", "round")):
-        assert np.array_equal(got[k], ref[k]), f"{name}: {np.sum(got[k] != ref[k])} of {n} differ"
+    out = torch.zeros((5, n), dtype=torch.float64, device="cuda")
+    for c0, c1 in ((0.2, 6.0), (0.1, 3.0), (0.7, 1.0 / 3.0), (float(np.nextafter(1.0, 0.0)), 0.30000000000000004)):
+        rc = L.pe_diag_norm2(n, C.c_void_p(ad.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(out.data_ptr()), c0, c1, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        want = list(ref) + [a / c0, b / c1]
+        for k, name in enumerate(("norm2", "divide", "round", f"div_const {c0}", f"div_const {c1}")):
+            same = (got[k] == want[k]) & (np.signbit(got[k]) == np.signbit(want[k]))
+            assert same.all(), f"{name}: {np.sum(~same)} of {n} differ"
 
 
 @pytest.mark.parametrize("group", ["20x20_p4", "40x40_p8"])
