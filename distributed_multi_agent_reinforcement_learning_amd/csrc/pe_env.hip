@@ -282,12 +282,15 @@ __device__ void dev_step(const pe_config &c, const SqThr &th, const Lds &l, int 
                 rn[1 + lane] = x;
                 outv = (x - x) / (x + 1e-8);
             } else {
+                // the two divisions by the sample count share one reciprocal (div_const is exact: n is an integer far below
+                // 2^53, so its significand is never all ones)
+                const double yn = 1.0 / n;
                 double old = rn[1 + lane];
-                double mean = old + (x - old) / n;
+                double mean = old + div_const(x - old, n, yn);
                 double S = rn[1 + P + lane] + (x - old) * (x - mean);
                 rn[1 + lane] = mean;
                 rn[1 + P + lane] = S;
-                outv = (x - mean) / (__builtin_sqrt(S / n) + 1e-8);
+                outv = (x - mean) / (__builtin_sqrt(div_const(S, n, yn)) + 1e-8);
             }
         }
         if (out.reward) out.reward[(int64_t)env * out.reward_stride + lane] = (float)outv;
