@@ -314,20 +314,38 @@ __device__ void dev_observe(const pe_config &c, const SqThr &th, const Lds &l, i
     if (o.p_state && lane < 4 * P) o.p_state[(int64_t)env * o.p_state_stride + lane] = (float)l.def[(lane & 3) * P + (lane >> 2)];
     if (o.e_state && lane < 4) o.e_state[(int64_t)env * o.e_state_stride + lane] = (float)l.eva[lane];
     // communicate(): upper-triangular range test plus the adj[j, 1] = 1 side effect
-    for (int idx = lane; idx < P * P; idx += WAVE) {
-        int i = idx / P, j = idx - i * P;
-        l.cond[idx] = (i <= j) && (norm2sq(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= th.comm_le);
-    }
-    for (int idx = lane; idx < (P * O) >> 2; idx += WAVE) ((uint32_t *)l.oadj)[idx] = 0u;  // O is a multiple of 4
-    wave_sync();
-    if (o.p_adj) {
+    if (P * P <= WAVE) {
+        // one pair per lane; the in-range bits stay in a 64-bit wave mask (no LDS round trip for the column-1 rule)
+        const int i = lane / P, j = lane - i * P;
+        const bool in_rng = lane < P * P && (i <= j) && (norm2sq(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= th.comm_le);
+        const unsigned long long cm = __ballot(in_rng);
+        for (int idx = lane; idx < (P * O) >> 2; idx += WAVE) ((uint32_t *)l.oadj)[idx] = 0u;  // O is a multiple of 4
+        if (o.p_adj && lane < P * P) {
+            bool v = in_rng;
+            if (j == 1) {  // adj[i, 1] is set whenever some row k <= i is in range of i (k == i always is)
+                unsigned long long col = 0ull;
+                for (int k = 0; k <= i; k++) col |= 1ull << (k * P + i);
+                v = v || ((cm & col) != 0ull);
+            }
+            o.p_adj[(int64_t)env * o.p_adj_stride + lane] = v ? 1.f : 0.f;
+        }
+        wave_sync();
+    } else {
         for (int idx = lane; idx < P * P; idx += WAVE) {
             int i = idx / P, j = idx - i * P;
-            bool v = l.cond[idx] != 0;
-            if (j == 1) {  // adj[i, 1] is set whenever some row k <= i is in range of i (k == i always is)
-                for (int k = 0; k <= i; k++) v = v || (l.cond[k * P + i] != 0);
+            l.cond[idx] = (i <= j) && (norm2sq(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= th.comm_le);
+        }
+        for (int idx = lane; idx < (P * O) >> 2; idx += WAVE) ((uint32_t *)l.oadj)[idx] = 0u;  // O is a multiple of 4
+        wave_sync();
+        if (o.p_adj) {
+            for (int idx = lane; idx < P * P; idx += WAVE) {
+                int i = idx / P, j = idx - i * P;
+                bool v = l.cond[idx] != 0;
+                if (j == 1) {  // adj[i, 1] is set whenever some row k <= i is in range of i (k == i always is)
+                    for (int k = 0; k <= i; k++) v = v || (l.cond[k * P + i] != 0);
+                }
+                o.p_adj[(int64_t)env * o.p_adj_stride + idx] = v ? 1.f : 0.f;
             }
-            o.p_adj[(int64_t)env * o.p_adj_stride + idx] = v ? 1.f : 0.f;
         }
     }
     // find_attacker(): rounded-cell range test + Bresenham line of sight over the static map (agent.py:157-169, 319-341)
@@ -364,9 +382,13 @@ __device__ void dev_observe(const pe_config &c, const SqThr &th, const Lds &l, i
             changed = lcache[lane * CW] != mycell;
         }
         const unsigned long long chg = __ballot(changed);
-        for (int i = 0; i < P; i++) {  // wave-uniform
+        // cached bits -> flag bytes, four obstacles (one LDS word) per lane and iteration; O is a multiple of 4, so a word
+        // never straddles two defenders
+        for (int wd = lane; wd < (P * O) >> 2; wd += WAVE) {
+            const int i = (4 * wd) / O, j = 4 * wd - i * O;
             if ((chg >> i) & 1ull) continue;
-            for (int j = lane; j < O; j += WAVE) l.oadj[i * O + j] = (uint8_t)((lcache[i * CW + 1 + (j >> 5)] >> (j & 31)) & 1u);
+            const uint32_t nib = (lcache[i * CW + 1 + (j >> 5)] >> (j & 31)) & 0xFu;
+            ((uint32_t *)l.oadj)[wd] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
         }
         const int n_chg = __popcll(chg);
         const int tasks = n_chg * c.num_beams;
