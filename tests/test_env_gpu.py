@@ -257,3 +257,49 @@ def test_device_reset_equals_host_reset(name, num_envs):
     ed.sim.meta.copy_(meta)
     ed.reset()
     assert all(torch.equal(a, b) for a, b in zip(ref, (ed.sim.grid, ed.sim.eva, ed.sim.tape)))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("P,W,H,blocks,variance", [
+    (2, 20, 20, 0, 4),      # fewest defenders the reference's communicate() allows, EMPTY map: no boundary obstacles at all
+    (16, 60, 60, 5, 12),    # PE_MAX_P defenders (16-wide register tiles, P * P > 64 code paths); on 40 x 40 some seeds make the
+                            # reference's defender placement loop forever, so the map is 60 x 60
+    (6, 18, 33, 4, 6),      # narrow non-square map, crowded: rejected moves, clipped proposals at the border, unreachable targets
+])
+def test_edge_configurations_match_oracle(P, W, H, blocks, variance):
+    """Domain edge cases against the CPU oracle, bit for bit, fused tick incl. replans: empty maps (n_obs == 0), the
+    minimum / maximum number of defenders, a narrow non-square crowded map (a still more crowded one, 8 defenders on 12 x 31
+    with 8 blocks, makes the reference's own defender placement loop forever -- not a configuration)."""
+    T, N = 32, 24
+    cfg = product_cfg(P, W, H, T, blocks=blocks, variance=variance, **{"map.center": [W // 2, H // 2]})
+    env = _env(cfg, N)
+    init = random_init(N, P, W, H, blocks, variance, seed=4242)
+    if blocks == 0:
+        assert int(init["n_obs"].max()) == 0
+    env.load(init, reset_reward_norm=True)
+    ocfg, oenvs = oracle_envs_from_init(init, P, W, H, T)
+    rng = np.random.default_rng(17)
+    obs = env.new_obs()
+    reward = torch.zeros((N, P), dtype=torch.float32, device="cuda")
+    raw = torch.zeros((N, P), dtype=torch.float32, device="cuda")
+    env.observe(obs); env.evader_step()
+    for t in range(T):
+        o_dev = {k: v.cpu().numpy() for k, v in obs.items()}
+        eva = env.eva.cpu().numpy(); meta = env.meta.cpu().numpy()
+        acts = rng.integers(0, 9, (N, P)).astype(np.int32)
+        for n, oe in enumerate(oenvs):
+            ps, es, pa, ea, oa = oe.observe()
+            oe.evader_step()
+            for key, ref in (("p_state", ps), ("e_state", es), ("p_adj", pa), ("e_adj", ea), ("o_adj", oa)):
+                assert np.array_equal(o_dev[key][n], ref), (key, t, n)
+            assert np.array_equal(eva[n], oe.state()["evader"]), (t, n)
+            assert meta[n, 1] == oe.state()["path_len"], (t, n)
+        env.tick(torch.as_tensor(acts).cuda(), obs, reward, raw)
+        r_raw = raw.cpu().numpy(); r_n = reward.cpu().numpy(); defs = env.defenders_aos().cpu().numpy()
+        for n, oe in enumerate(oenvs):
+            r, ok, _ = oe.step(acts[n])
+            assert np.array_equal(r_raw[n], r.astype(np.float32)), (t, n)
+            assert np.array_equal(r_n[n], oe.reward_norm(r).astype(np.float32)), (t, n)
+            assert np.array_equal(defs[n], oe.state()["defenders"]), (t, n)
+    assert not env.status().any().item()
