@@ -291,3 +291,31 @@ def test_ppo_loss_matches_autograd_oracle(value_clip):
     torch.testing.assert_close(lc2.cpu(), lc.detach(), rtol=1e-5, atol=1e-6)
     for got, want in ((ad.grad, a.grad), (ed.grad, e.grad), (vd.grad, v.grad)):
         torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_msg_agg_empty_neighbourhoods():
+    """Obstacle relation of an EMPTY map: kvalid == 0 (critic, rollout form) and an all-zero adjacency (actor) aggregate to
+    exact zeros (F.normalize's 1e-12 clamp), with zero parameter gradients; mixed with rows that do have neighbours."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(3)
+    N, P, O, E = 6, 8, 176, 128
+    p = (torch.randn(N, P, 4) * 10 + 20).cuda()
+    o = torch.zeros(N, O, 4).cuda()
+    kvalid = torch.tensor([0, 0, 7, 0, 176, 1], dtype=torch.int32).cuda()
+    for n in range(N):
+        o[n, :int(kvalid[n]), :2] = torch.randint(0, 40, (int(kvalid[n]), 2)).float().cuda()
+    W = (torch.randn(E, 4) * 0.3).cuda().requires_grad_(True)
+    b = (torch.randn(E) * 0.1).cuda().requires_grad_(True)
+    out = ops.msg_agg(p, o, None, None, W, b, ops.ADJ_VALID, kvalid, 1)
+    empty = (kvalid == 0)
+    assert torch.equal(out[empty], torch.zeros_like(out[empty])) and out[~empty].abs().sum() > 0
+    ref = _ref_msg_agg(p[:, None].cpu(), o[:, None].cpu(), None,
+                       (torch.arange(O)[None, None, None, :] < kvalid.cpu()[:, None, None, None]).float().expand(N, 1, P, O),
+                       W.detach().cpu(), b.detach().cpu(), False)
+    assert torch.allclose(out.cpu(), ref[:, 0], rtol=2e-5, atol=2e-5)
+    out[empty].sum().backward()
+    assert torch.equal(W.grad, torch.zeros_like(W.grad)) and torch.equal(b.grad, torch.zeros_like(b.grad))
+    adj = torch.zeros(N, P, O).cuda()
+    z = ops.msg_agg(p, o, None, adj, W, b, ops.ADJ_TENSOR, None, 1)
+    assert torch.equal(z, torch.zeros_like(z))
