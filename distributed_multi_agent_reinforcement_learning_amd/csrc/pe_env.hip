@@ -1327,6 +1327,10 @@ int pe_diag_norm2(int32_t n, const double *a, const double *b, double *out, doub
     return (int)hipGetLastError();
 }
 
+// diagnostics (host only, no GPU needed): the comparison thresholds / reciprocals launch() hands to the tick kernel
+double pe_diag_sq_threshold(double r, int32_t strict) { return sq_threshold(r, strict != 0); }
+double pe_diag_div_reciprocal(double b) { return div_const_reciprocal(b); }
+
 const char *pe_error_string(int code) {
     if (code == PE_ERR_BAD_CONFIG) return "pe_env: configuration outside kernel limits";
     if (code == PE_ERR_NULL) return "pe_env: null argument";
