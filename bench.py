@@ -5,23 +5,29 @@ in the loop (fused HIP env tick + batched actor/critic forward), GAE, PPO-clip/v
 samples, gradient all-reduce (RCCL) and the Adam step.  value = env-steps of all ranks / wall time.
 Synthetic data: seeded random maps, random-init weights (no datasets or checkpoints exist for this workload).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3] [--num-envs E] [--no-cpu-baseline]
-Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3] [--num-envs E] [--no-cpu-baseline] [--no-secondary]
+
+`--gpus N` with N > 1 starts its own N rank processes (a `torch.distributed.run` child, one rank per GPU over RCCL) before
+anything in this process touches the GPU; under an outer `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
+The headline line is BASELINE config 2 (depth 0, "GRU"); the same line carries `configs.cfg3` (DHGN depth 3, the
+configuration with end-to-end reference parity) measured the same way right after it.
 """
 import argparse
+import gc
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_PEAK_TF = 157.3    # fp32 vector == fp32 MFMA peak
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_tick_pmc.json")
 
 
 def algorithmic_bytes_per_env_step(P, W, H, O):
@@ -31,9 +37,37 @@ def algorithmic_bytes_per_env_step(P, W, H, O):
     return reads + writes
 
 
+def tick_kernel_hash():
+    """identifies the environment kernel source a PMC capture belongs to"""
+    h = hashlib.sha256()
+    for rel in ("distributed_multi_agent_reinforcement_learning_amd/csrc/pe_env.hip", "include/pe_env.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_traffic(N, us_live):
+    """HBM bytes per launch of the regular tick from the committed rocprofv3 PMC passes (tools/pmc_summary.py; FETCH_SIZE
+    doubled per MI355X_MICROARCH.md, WRITE_SIZE as read).  Counters cannot be collected inside this process, so the record
+    is only used when it was captured on THIS kernel source (hash) at this size and its launch duration agrees with the
+    live one; otherwise traffic is null and the reason is reported."""
+    try:
+        j = json.load(open(PMC_FILE))
+    except Exception:
+        return None, "no PMC record (profiles/r02_tick_pmc.json)"
+    if j.get("num_envs") != N:
+        return None, f"PMC record is for {j.get('num_envs')} environments"
+    if j.get("kernel_hash") != tick_kernel_hash():
+        return None, "PMC record is stale: csrc/pe_env.hip / include/pe_env.h changed since it was captured"
+    us_rec = j.get("us_per_launch")
+    if us_rec and abs(us_rec - us_live) > 0.25 * us_live:
+        return None, f"PMC record's launch duration ({us_rec:.1f} us) disagrees with the live run ({us_live:.1f} us)"
+    return j["traffic_bytes_per_launch"], None
+
+
 def measure_env_tick(trainer, n_ticks):
     """Launch durations of the fused env tick (HIP events on the launch stream; random actions, policy excluded):
-    the regular tick k_tick<step,observe,evader> and the replan variant that runs every `difficulty` ticks."""
+    the regular tick and the replan variant that runs every `difficulty` ticks; plus the A* work of the last replan."""
+    import torch
     env = trainer.env
     N, P, D = env.num_envs, env.num_defender, env.pe_cfg.difficulty
     env.reset()
@@ -56,12 +90,18 @@ def measure_env_tick(trainer, n_ticks):
     dur = [ev[t].elapsed_time(ev[t + 1]) * 1e-3 for t in range(n_ticks)]
     reg = [d for d, k in zip(dur, kinds) if not k]
     rep = [d for d, k in zip(dur, kinds) if k]
-    return sum(reg) / max(1, len(reg)), (sum(rep) / len(rep) if rep else float("nan")), sum(dur) / n_ticks
+    exp = env.sim.meta[:, 5].float()
+    return dict(regular=sum(reg) / max(1, len(reg)), replan=(sum(rep) / len(rep) if rep else float("nan")),
+                replan_max=max(rep) if rep else float("nan"), avg=sum(dur) / n_ticks,
+                astar_exp_mean=float(exp.mean()), astar_exp_max=float(exp.max()))
 
 
 def measure_compute_kernels(trainer, cfg):
-    """Isolated timings of the two compute-bound hand-written kernels at the update's mini-batch shape, priced against the
-    fp32 MFMA / vector peak (157.3 TFLOP/s, MI355X_MICROARCH.md) with the ALGORITHMIC flops of SURVEY 8(d)."""
+    """Isolated timings of the compute-bound hand-written kernels at the update's mini-batch shape against the 157.3 TFLOP/s
+    fp32 MFMA / vector peak, ALGORITHMIC flops of SURVEY 8(d) (and the executed flops where the kernel evaluates fewer)."""
+    import ctypes as C
+    import torch
+    from types import SimpleNamespace
     from distributed_multi_agent_reinforcement_learning_amd import ops
     dev = trainer.device
     T, P, O, E = cfg.env.max_steps, cfg.env.num_defender, cfg.map.num_max_obstacle, cfg.algo.embedding_dim
@@ -75,6 +115,10 @@ def measure_compute_kernels(trainer, cfg):
             fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3
+
+    def entry(kernel, fl, t, bound="mfma", **kw):
+        return dict(bound=bound, kernel=kernel, achieved=round(fl / t / 1e12, 2), peak=FP32_PEAK_TF, unit="TFLOP/s",
+                    frac=round(fl / t / (FP32_PEAK_TF * 1e12), 4), us_per_launch=round(t * 1e6, 1), **kw)
     out = {}
     if E == 128 and cfg.algo.rnn_hidden_dim == 128:
         B = mb * P
@@ -82,66 +126,51 @@ def measure_compute_kernels(trainer, cfg):
         gi = torch.randn(T, B, 384, device=dev)
         o = torch.empty(T, B, 128, device=dev)
         L = ops.load_library()
-        import ctypes as C
         ptr = lambda t: C.c_void_p(t.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         w, b = torch.randn(384, 128, device=dev) * 0.08, torch.zeros(384, device=dev)
         t = timeit(lambda: L.gru_seq_fwd(T, B, 128, ptr(gi), ptr(w), ptr(b), ptr(h0[0]), ptr(o), None, st))
-        fl = 2.0 * T * B * 128 * 384
-        out["gru_seq_fwd"] = {"bound": "mfma", "kernel": "k_gru_seq_fwd (recurrent GEMM h W_hh^T + gates, T steps in one launch)",
-                              "achieved": round(fl / t / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4),
-                              "us_per_launch": round(t * 1e6, 1), "rows": B, "steps": T}
+        out["gru_seq_fwd"] = entry("k_gru_seq_fwd (recurrent GEMM h W_hh^T + gates, T steps in one launch)", 2.0 * T * B * 128 * 384, t,
+                                   rows=B, steps=T)
         Kr = mb * T * P  # rows of one mini-batch: the weight gradient of a GRU projection reduces over all of them
         ga = torch.randn(Kr, 384, device=dev); xa = torch.randn(Kr, 128, device=dev)
         t = timeit(lambda: ops.wgrad(ga, xa))
-        fl = 2.0 * Kr * 384 * 128
-        out["wgrad"] = {"bound": "mfma", "kernel": "k_wgrad<3,1> + reduce (dW_ih [384][128] = dgi^T x over the mini-batch rows, split-K)",
-                        "achieved": round(fl / t / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4),
-                        "us_per_launch": round(t * 1e6, 1), "rows": Kr, "hbm_GBps": round((384 + 128) * 4.0 * Kr / t / 1e9, 1)}
+        out["wgrad"] = entry("k_wgrad<3,1> + reduce (dW_ih [384][128] = dgi^T x over the mini-batch rows, split-K)", 2.0 * Kr * 384 * 128, t,
+                             rows=Kr, hbm_GBps=round((384 + 128) * 4.0 * Kr / t / 1e9, 1))
         del ga, xa
         Br = trainer.num_envs * P
-        from types import SimpleNamespace  # raw tensors: constructing torch.nn.GRU on the device initialises MIOpen
         gm = SimpleNamespace(num_layers=1, weight_ih_l0=torch.randn(384, 128, device=dev) * 0.08, weight_hh_l0=torch.randn(384, 128, device=dev) * 0.08,
                              bias_ih_l0=torch.zeros(384, device=dev), bias_hh_l0=torch.zeros(384, device=dev))
         xr = torch.randn(1, Br, 128, device=dev); hr = torch.randn(1, Br, 128, device=dev)
         with torch.no_grad():
             t = timeit(lambda: ops.gru(xr, hr, gm), n=20)
-        fl = 2.0 * Br * 128 * 768
-        out["gru_cell"] = {"bound": "mfma", "kernel": "k_gru_cell (one rollout GRU layer step: both projections + gates, one launch)",
-                           "achieved": round(fl / t / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4),
-                           "us_per_launch": round(t * 1e6, 1), "rows": Br}
+        out["gru_cell"] = entry("k_gru_cell (one rollout GRU layer step: both projections + gates, one launch)", 2.0 * Br * 128 * 768, t, rows=Br)
     R = mb * T
     p = torch.rand(R, P, 4, device=dev) * 40; q = torch.rand(mb, O, 4, device=dev) * 40
     W = torch.randn(E, 4, device=dev) * 0.3; bb = torch.zeros(E, device=dev)
     with torch.no_grad():
         t = timeit(lambda: ops.msg_agg(p, q, None, None, W, bb, ops.ADJ_ONES, None, T))
-    fl = R * P * O * (2 * 4 * E + 3 * E)
-    out["msg_agg_fwd"] = {"bound": "mfma", "kernel": "k_msg_agg_fwd<8> (critic obstacle relation, dense)", "achieved": round(fl / t / 1e12, 2),
-                          "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / t / 157.3e12, 4), "us_per_launch": round(t * 1e6, 1), "rows": R,
-                          "note": "algorithmic flops of the reference formulation W(p_i - q_j); the kernel evaluates c_i - d_j (fewer)"}
+    fl_alg = R * P * O * (2 * 4 * E + 3 * E)
+    out["msg_agg_fwd"] = entry("dhgn_msg_agg_fwd, critic obstacle relation (all-ones adjacency over O slots)", fl_alg, t, bound="valu", rows=R,
+                               note="`achieved` prices the reference formulation W (p_i - q_j) + b -> relu -> mean (11 E flops per pair, "
+                                    "SURVEY 8d): an algorithmic-equivalent rate, not a hardware fraction; the kernel executes fewer flops")
     return out
 
 
-def load_pmc_traffic(N):
-    """HBM bytes per launch of the regular tick from the committed rocprofv3 PMC passes (profiles/r01_tick_pmc.json,
-    produced with tools/profile_tick.py; FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as read)."""
-    path = os.path.join(ROOT, "profiles", "r01_tick_pmc.json")
-    try:
-        j = json.load(open(path))
-        if j.get("num_envs") == N:
-            return j["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
-
-
-def cpu_baseline(cfg, n_envs, T, threads):
-    """The same path on the host: CPU oracle env (C) + plain-torch oracle model, rollout + one update, bounded sample."""
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the same path on the host, one process per core, bounded sample
+def cpu_worker(config, n_envs, T, seed0):
+    """One host process, one thread: CPU oracle env (C) + plain-torch oracle model; rollout of n_envs episodes + one PPO
+    update pass over them.  Prints one JSON line.  Never touches the GPU."""
+    import random
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
     from oracle import model_oracle as mo
     from oracle import pe_oracle, reset_oracle
-    import random
-    torch.set_num_threads(threads)
+    from distributed_multi_agent_reinforcement_learning_amd.config import baseline_config
     from distributed_multi_agent_reinforcement_learning_amd.model import build_actor_critic
+    cfg = baseline_config(config)
     P, (W, H), O, d = cfg.env.num_defender, cfg.map.map_size, cfg.map.num_max_obstacle, cfg.algo.depth
     E, Hd, L = cfg.algo.embedding_dim, cfg.algo.rnn_hidden_dim, cfg.algo.num_layers
     torch.manual_seed(0)
@@ -158,7 +187,7 @@ def cpu_baseline(cfg, n_envs, T, threads):
     t0 = time.time()
     with torch.no_grad():
         for n in range(n_envs):
-            random.seed(n); np.random.seed(n)
+            random.seed(seed0 + n); np.random.seed(seed0 + n)
             r0 = reset_oracle.reset_oracle(W, H, P, cfg.map.num_obstacle_block, list(cfg.map.center), cfg.map.variance, tape_len=16)
             oe = pe_oracle.OracleEnv(ocfg)
             oe.load(r0["grid"], r0["obs_xy"], r0["defenders"], r0["evader"], r0["target"], r0["tape"])
@@ -188,36 +217,63 @@ def cpu_baseline(cfg, n_envs, T, threads):
                 buf["actor_historical_embedding"][n, t + d] = a_cur; buf["critic_historical_embedding"][n, t + d] = c_cur
     t_roll = time.time() - t0
     t0 = time.time()
-    mo.train(sd_a, sd_c, buf, d, max(1, n_envs // 2), cfg.algo.gamma, cfg.algo.lamda, cfg.algo.epsilon, cfg.algo.entropy_coef)
+    mo.train(sd_a, sd_c, buf, d, 1, cfg.algo.gamma, cfg.algo.lamda, cfg.algo.epsilon, cfg.algo.entropy_coef)
     t_train = time.time() - t0
-    return n_envs * T / (t_roll + t_train), t_roll, t_train
+    print(json.dumps({"cpu_worker": True, "steps": n_envs * T, "t_roll": t_roll, "t_train": t_train}), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3"])
-    ap.add_argument("--num-envs", type=int, default=None, help="environments per GPU (default: the config's)")
-    ap.add_argument("--max-steps", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tick-samples", type=int, default=150)
-    args = ap.parse_args()
+def cpu_baseline(config, T, envs_per_proc=4):
+    """One single-threaded process per host core, all at once (the reference runs one Ray worker per core, main.py:42-62)."""
+    cores = max(1, min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", config, str(envs_per_proc), str(T), str(1000 * (i + 1))],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT) for i in range(cores)]
+    res = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        lines = [l for l in so.splitlines() if l.startswith('{"cpu_worker"')]
+        if p.returncode != 0 or not lines:
+            raise RuntimeError("cpu baseline worker failed: " + se[-1500:])
+        res.append(json.loads(lines[-1]))
+    wall = max(r["t_roll"] + r["t_train"] for r in res)
+    steps = sum(r["steps"] for r in res)
+    return dict(value=round(steps / wall, 2), unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{cores} single-threaded processes at once (one per host core), each {envs_per_proc} envs x {T} steps: oracle C env + "
+                       f"plain-torch model rollout (max {max(r['t_roll'] for r in res):.1f}s) + one PPO update pass over its episodes "
+                       f"(max {max(r['t_train'] for r in res):.1f}s); value = all steps / slowest process")
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    """--gpus N > 1 outside a launcher: start the N ranks as a child job (nothing here has touched the GPU) and relay it."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
+def run_config(name, args, with_roofline):
+    """2 set-up iterations (graph capture, allocator growth: once per process) + W warm-up + exactly K timed iterations,
+    bracketed by barrier + synchronize, MAX over ranks.  Returns the result dict (rank 0 fills the JSON from it)."""
+    import torch
+    import torch.distributed as dist
     from distributed_multi_agent_reinforcement_learning_amd.config import baseline_config
     from distributed_multi_agent_reinforcement_learning_amd.trainer import Trainer, dist_env
-
     rank, local_rank, world = dist_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     ov = {}
     if args.num_envs:
         ov["runtime.num_envs"] = args.num_envs
     if args.max_steps:
         ov["env.max_steps"] = args.max_steps
-    cfg = baseline_config(args.config, **ov)
+    cfg = baseline_config(name, **ov)
     tr = Trainer(cfg)  # weak scaling: every rank owns runtime.num_envs environments
     N, T, P = tr.num_envs, cfg.env.max_steps, cfg.env.num_defender
     W, H = cfg.map.map_size
@@ -228,12 +284,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Set-up, not a benchmark step: the first iteration captures the rollout hipGraph and builds every autograd / optimiser
-    # buffer, and the caching allocator still grows its segment pool (device mallocs, +8 GB at cfg3) during the iteration
-    # after it; both happen once per process.  The W warm-up steps and the K timed steps below are then steady state.
-    for _ in range(2):
-        tr.iterate()
-    for _ in range(args.warmup):
+    for _ in range(2 + args.warmup):
         tr.iterate()
     barrier()
     t0 = time.perf_counter()
@@ -247,40 +298,84 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=tr.device if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-
     rollout_ms, update_ms = tr.last_breakdown_ms()
-    # roofline of the environment tick kernel: algorithmic bytes / measured launch duration
-    t_tick, t_replan, t_avg = measure_env_tick(tr, args.tick_samples)
-    bytes_per_step = algorithmic_bytes_per_env_step(P, W, H, O)
-    achieved = N * bytes_per_step / t_tick / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_tick<step,observe,evader,no-replan> (csrc/pe_env.hip)", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": load_pmc_traffic(N) if args.config in ("cfg2", "cfg3") else None,
-                "bytes_per_env_step": bytes_per_step, "us_per_launch": round(t_tick * 1e6, 2), "env_steps_per_launch": N,
-                "replan_tick_us_per_launch": round(t_replan * 1e6, 2), "episode_avg_tick_us": round(t_avg * 1e6, 2)}
-    extra = measure_compute_kernels(tr, cfg) if rank == 0 else {}
+    res = dict(value=round(env_steps / dt, 1), ms_per_step=round(dt / args.steps * 1e3, 2),
+               ppo_updates_per_s=round(args.steps * cfg.algo.epochs / dt, 4),
+               breakdown_ms={"rollout_incl_reset": round(rollout_ms, 1), "gae_ppo_update_allreduce_adam": round(update_ms, 1)},
+               workload=f"{name}: pursuit_evasion_game {P} defenders, {W}x{H} map, {N} envs/GPU, T={T}, DHGN depth {cfg.algo.depth} + "
+                        f"2-layer GRU actor/critic, rollout + PPO update",
+               envs_per_gpu=N, episode_steps=T, mini_batch_size=tr.mini_batch_size, backend=(dist.get_backend() if world > 1 else None))
+    if with_roofline:
+        tk = measure_env_tick(tr, args.tick_samples)
+        bytes_per_step = algorithmic_bytes_per_env_step(P, W, H, O)
+        achieved = N * bytes_per_step / tk["regular"] / 1e9
+        traffic, why = load_pmc_traffic(N, tk["regular"] * 1e6)
+        res["roofline"] = {"bound": "hbm", "kernel": "k_tick<step,observe,evader,no-replan> (csrc/pe_env.hip)", "achieved": round(achieved, 2),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "bytes_per_env_step": bytes_per_step, "us_per_launch": round(tk["regular"] * 1e6, 2), "env_steps_per_launch": N,
+                           "episode_avg_tick_us": round(tk["avg"] * 1e6, 2)}
+        if why:
+            res["roofline"]["traffic_note"] = why
+        res["roofline_replan_tick"] = {"kernel": "k_tick<..., replan> (rescan + weighted A* of every evader, every `difficulty` ticks)",
+                                       "bound": "instruction issue of the slowest wave (stragglers), not bytes",
+                                       "us_per_launch": round(tk["replan"] * 1e6, 1), "us_max": round(tk["replan_max"] * 1e6, 1),
+                                       "astar_expansions_mean": round(tk["astar_exp_mean"], 1), "astar_expansions_max": tk["astar_exp_max"]}
+        if rank == 0:
+            res["roofline_compute_kernels"] = measure_compute_kernels(tr, cfg)
+    del tr
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
-    out = None
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3"])
+    ap.add_argument("--num-envs", type=int, default=None, help="environments per GPU (default: the config's)")
+    ap.add_argument("--max-steps", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 measurement that rides along with cfg2")
+    ap.add_argument("--tick-samples", type=int, default=150)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ
+    world_env = int(os.environ.get("WORLD_SIZE", 1))
+    if launched and world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE={world_env} of the launcher")
+    if not launched and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
+
+    import torch.distributed as dist
+    from distributed_multi_agent_reinforcement_learning_amd.trainer import dist_env
+    rank, local_rank, world = dist_env()
+    main_res = run_config(args.config, args, with_roofline=True)
+    second = None
+    if args.config == "cfg2" and not args.no_secondary:
+        second = run_config("cfg3", args, with_roofline=False)
     if rank == 0:
         out = {
-            "metric": "env-steps/sec (whole node), pursuit-evasion 8-agent 4096-env", "value": round(env_steps / dt, 1),
+            "metric": "env-steps/sec (whole node), pursuit-evasion 8-agent 4096-env", "value": main_res["value"],
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 environment / f32 policy", "data": "synthetic (seeded random maps, random-init weights)",
-            "config": {"workload": f"{args.config}: pursuit_evasion_game {P} defenders, {W}x{H} map, {N} envs/GPU, T={T}, "
-                                   f"DHGN depth {cfg.algo.depth} + 2-layer GRU actor/critic, rollout + PPO update",
-                       "envs_per_gpu": N, "episode_steps": T, "mini_batch_size": tr.mini_batch_size, "parallelism": f"dp{world}"},
-            "ppo_updates_per_s": round(args.steps * cfg.algo.epochs / dt, 4),
-            "breakdown_ms": {"rollout_incl_reset": round(rollout_ms, 1), "gae_ppo_update_allreduce_adam": round(update_ms, 1)},
-            "roofline": roofline,
-            "roofline_compute_kernels": extra,
+            "config": {"workload": main_res["workload"], "envs_per_gpu": main_res["envs_per_gpu"], "episode_steps": main_res["episode_steps"],
+                       "mini_batch_size": main_res["mini_batch_size"], "parallelism": f"dp{world}",
+                       "collective": (f"torch.distributed {main_res['backend']} all_reduce(SUM) of one flat fp32 gradient bucket per epoch"
+                                      if world > 1 else None)},
+            "ppo_updates_per_s": main_res["ppo_updates_per_s"], "breakdown_ms": main_res["breakdown_ms"],
+            "roofline": main_res["roofline"], "roofline_replan_tick": main_res["roofline_replan_tick"],
+            "roofline_compute_kernels": main_res.get("roofline_compute_kernels", {}),
         }
+        if second is not None:
+            out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "workload")}}
         if not args.no_cpu_baseline and world == 1:
-            threads = min(16, os.cpu_count() or 1)
-            v, t_roll, t_train = cpu_baseline(cfg, 6, min(T, 150), threads)
-            out["cpu_baseline"] = {"value": round(v, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
-                                   "sample": f"6 envs x {min(T, 150)} steps: oracle C env + plain-torch model rollout ({t_roll:.1f}s) "
-                                             f"+ one PPO update pass ({t_train:.1f}s) on the host"}
+            out["cpu_baseline"] = cpu_baseline(args.config, min(main_res["episode_steps"], 150))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -50,7 +50,8 @@ def load_config(path=None, **overrides):
     rt.setdefault("reference_quirks", True)
     rt.setdefault("use_graphs", True)
     rt.setdefault("device_reset", True)           # episode reset on the GPU (k_reset); False = host resetter, same results
-    rt.setdefault("overlap_actor_critic", False)  # update: critic branch on a second stream (see mappo.MAPPO)
+    if rt.get("overlap_actor_critic"):
+        raise ValueError("runtime.overlap_actor_critic was removed: the two-stream update could stall (DESIGN.md)")
     for k, v in overrides.items():
         node = cfg
         parts = k.split(".")

@@ -19,6 +19,7 @@
 #include <cmath>
 
 #include "pe_env.h"
+#include "pe_env_diag.h"
 
 namespace {
 
@@ -806,7 +807,9 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
 }
 
 // bidx from the obstacle list (pursuit_env.py:21: index == position in np.argwhere order)
-__global__ void k_build_bidx(const pe_config c, const pe_state st, const int32_t *obs_xy) {
+struct DevRng;
+__device__ int dev_rng_status(const DevRng *rng, int env);
+__global__ void k_build_bidx(const pe_config c, const pe_state st, const int32_t *obs_xy, const DevRng *rng) {
     const int env = blockIdx.x;
     const int WH = c.W * c.H;
     int16_t *b = st.bidx + (size_t)env * WH;
@@ -817,7 +820,9 @@ __global__ void k_build_bidx(const pe_config c, const pe_state st, const int32_t
         int x = obs_xy[((size_t)env * c.O + k) * 2], y = obs_xy[((size_t)env * c.O + k) * 2 + 1];
         if (x >= 0 && x < c.W && y >= 0 && y < c.H) b[x * c.H + y] = (int16_t)k;
     }
-    if (threadIdx.x < PE_META_INTS) st.meta[(size_t)env * PE_META_INTS + threadIdx.x] = 0;
+    // a fresh meta record; on the device-reset path the status bits raised so far stay (sticky, see pe_env.h)
+    if (threadIdx.x < PE_META_INTS)
+        st.meta[(size_t)env * PE_META_INTS + threadIdx.x] = (threadIdx.x == PE_META_STATUS && rng) ? dev_rng_status(rng, env) : 0;
     if (threadIdx.x < PE_WP_WINDOW) st.wpw[(size_t)env * PE_WP_WINDOW + threadIdx.x] = 0u;
     if (threadIdx.x < c.P) st.lcache[((size_t)env * c.P + threadIdx.x) * (1 + (c.O + 31) / 32)] = 0xFFFFFFFFu;  // empty LiDAR cache
 }
@@ -919,9 +924,12 @@ int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, con
 // within 1 ulp of glibc's, which can only matter if a block centre lands within 1 ulp of a rounding boundary.
 struct DevRng {
     uint32_t py_mt[624], np_mt[624], snap_mt[624];
-    int32_t py_idx, np_idx, snap_idx, has_gauss, has_tape, pad;
+    int32_t py_idx, np_idx, snap_idx, has_gauss, has_tape;
+    int32_t status;  // sticky PE_STATUS_* bits of every episode since pe_env_reset_seed (k_build_bidx copies them into meta)
     double gauss;
 };
+
+__device__ int dev_rng_status(const DevRng *rng, int env) { return rng[env].status; }
 
 __device__ uint32_t mt_next(uint32_t *mt, int &idx) {  // lane 0 only
     if (idx >= 624) {
@@ -950,12 +958,14 @@ __device__ double np_random_sample(uint32_t *mt, int &idx) {
     return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 // base_env.py:52-70 on lane 0: first free cell of the inflated map
-__device__ void draw_target_l0(int W, int H, const uint8_t *infl, uint32_t *mt, int &idx, int &tx, int &ty) {
-    for (;;) {
+// false: PE_RESET_MAX_DRAWS candidates were all occupied (the last one is kept), like the host resetter
+__device__ bool draw_target_l0(int W, int H, const uint8_t *infl, uint32_t *mt, int &idx, int &tx, int &ty) {
+    for (int draws = 0; draws < PE_RESET_MAX_DRAWS; draws++) {
         tx = (int)py_randbelow(mt, idx, (uint32_t)W);
         ty = (int)py_randbelow(mt, idx, (uint32_t)H);
-        if (infl[tx * H + ty] == 0) return;
+        if (infl[tx * H + ty] == 0) return true;
     }
+    return false;
 }
 
 __host__ __device__ inline size_t reset_lds_bytes(const pe_config &c) {
@@ -985,6 +995,8 @@ __global__ __launch_bounds__(64) void k_reset(const pe_config c, const pe_state 
     double gauss = R.gauss;
     if (rewind) for (int i = lane; i < WH; i += WAVE) infs[i] = bank[i];
     wave_sync();
+    int fail = 0;  // lane 0: a placement loop gave up
+    if (!first && lane == 0) fail = st.meta[(size_t)env * PE_META_INTS + PE_META_STATUS] | R.status;  // carried over (sticky)
     if (rewind && lane == 0) {  // the reference draws a new target only on arrival: give the unused tape draws back
         const int consumed = st.meta[(size_t)env * PE_META_INTS + PE_META_TAPE_POS];
         int tx, ty;
@@ -1063,12 +1075,12 @@ __global__ __launch_bounds__(64) void k_reset(const pe_config c, const pe_state 
     {
         int tx = 0, ty = 0;
         if (lane == 0) {
-            draw_target_l0(W, H, infl, pym, pyi, tx, ty);
+            if (!draw_target_l0(W, H, infl, pym, pyi, tx, ty)) fail |= PE_STATUS_RESET_FAILED;
             st.target[2 * env] = tx; st.target[2 * env + 1] = ty;
         }
     }
     // init_defender (base_env.py:72-120)
-    int placed = 0, ncells = 0;
+    int placed = 0, ncells = 0, draws = 0;  // wave-uniform
     double *da = def_aos + (size_t)env * P * 4;
     while (placed < P) {
         double px = 0.0, pyv = 0.0;
@@ -1076,7 +1088,8 @@ __global__ __launch_bounds__(64) void k_reset(const pe_config c, const pe_state 
         px = __shfl(px, 0); pyv = __shfl(pyv, 0);
         const int cxi = py_round(px), cyi = py_round(pyv);
         bool ok = false;
-        if (infl[cxi * H + cyi] == 0) {
+        if (++draws > PE_RESET_MAX_DRAWS) { ok = true; fail |= PE_STATUS_RESET_FAILED; }  // give up: keep this candidate
+        else if (infl[cxi * H + cyi] == 0) {
             if (placed == 0) {
                 ok = true;
             } else {
@@ -1106,10 +1119,19 @@ __global__ __launch_bounds__(64) void k_reset(const pe_config c, const pe_state 
         }
     }
     // init_attacker (base_env.py:122-162), is_percepted=True: free cell within sensing range of a defender cell
+    draws = 0;
     for (;;) {
         double px = 0.0, pyv = 0.0;
         if (lane == 0) { px = np_random_sample(npm, npi) * (double)(W - 1); pyv = np_random_sample(npm, npi) * (double)(H - 1); }
         px = __shfl(px, 0); pyv = __shfl(pyv, 0);
+        if (++draws > PE_RESET_MAX_DRAWS) {
+            if (lane == 0) {
+                double *e = st.eva + (size_t)env * 4;
+                e[0] = px; e[1] = pyv; e[2] = 0.0; e[3] = 0.0;
+            }
+            fail |= PE_STATUS_RESET_FAILED;
+            break;
+        }
         if (infl[py_round(px) * H + py_round(pyv)] != 0) continue;
         const bool hit = lane < ncells && norm2((double)cells[2 * lane] - px, (double)cells[2 * lane + 1] - pyv) < c.def_sen_range;
         if (__ballot(hit) != 0ull) {
@@ -1130,10 +1152,11 @@ __global__ __launch_bounds__(64) void k_reset(const pe_config c, const pe_state 
         int32_t *tape = st.tape + (size_t)env * c.tape_len * 2;
         for (int k = 0; k < c.tape_len; k++) {
             int tx, ty;
-            draw_target_l0(W, H, infs, pym, pyi, tx, ty);
+            if (!draw_target_l0(W, H, infs, pym, pyi, tx, ty)) fail |= PE_STATUS_RESET_FAILED;
             tape[2 * k] = tx; tape[2 * k + 1] = ty;
         }
         R.py_idx = pyi; R.np_idx = npi; R.has_gauss = has_gauss; R.gauss = gauss;
+        R.status = fail;
     }
     wave_sync();
     for (int i = lane; i < 624; i += WAVE) { R.py_mt[i] = pym[i]; R.np_mt[i] = npm[i]; }
@@ -1172,7 +1195,7 @@ __global__ void k_reset_seed(int N, const uint64_t *seeds, DevRng *rng) {
         mt[0] = 0x80000000u;
         R.py_idx = 624;
     }
-    R.snap_idx = 624; R.has_gauss = 0; R.has_tape = 0; R.pad = 0; R.gauss = 0.0;
+    R.snap_idx = 624; R.has_gauss = 0; R.has_tape = 0; R.status = 0; R.gauss = 0.0;
 }
 
 }  // namespace
@@ -1237,7 +1260,7 @@ int pe_env_reset(const pe_config *cfg, const pe_state *st, const pe_reset_params
     DevRng *rng = (DevRng *)reset_state;
     uint8_t *bank = (uint8_t *)reset_state + N * sizeof(DevRng);
     hipLaunchKernelGGL(k_reset, dim3(N), dim3(WAVE), lds, s, *cfg, *st, *prm, rng, bank, (int)first, d_obs, d_def, o_state);
-    hipLaunchKernelGGL(k_build_bidx, dim3(N), dim3(256), 0, s, *cfg, *st, (const int32_t *)d_obs);
+    hipLaunchKernelGGL(k_build_bidx, dim3(N), dim3(256), 0, s, *cfg, *st, (const int32_t *)d_obs, (const DevRng *)rng);
     int tot = (int)(N * P * 4);
     hipLaunchKernelGGL(k_def_aos_to_soa, dim3((tot + 255) / 256), dim3(256), 0, s, (int)N, (int)P, (const double *)d_def, st->def);
     if (reset_rn) PE_TRY(hipMemsetAsync(st->rn, 0, N * (1 + 2 * P) * sizeof(double), s));
@@ -1267,7 +1290,7 @@ int pe_env_load(const pe_config *cfg, const pe_state *st, const pe_host_init *h,
     PE_TRY(hipMallocAsync((void **)&d_def, N * P * 4 * sizeof(double), s));
     PE_TRY(hipMemcpyAsync(d_obs, h->obs_xy, N * cfg->O * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     PE_TRY(hipMemcpyAsync(d_def, h->def, N * P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_build_bidx, dim3(N), dim3(256), 0, s, *cfg, *st, d_obs);
+    hipLaunchKernelGGL(k_build_bidx, dim3(N), dim3(256), 0, s, *cfg, *st, (const int32_t *)d_obs, (const DevRng *)nullptr);
     int tot = (int)(N * P * 4);
     hipLaunchKernelGGL(k_def_aos_to_soa, dim3((tot + 255) / 256), dim3(256), 0, s, (int)N, (int)P, d_def, st->def);
     if (h->reset_rn) PE_TRY(hipMemsetAsync(st->rn, 0, N * (1 + 2 * P) * sizeof(double), s));
@@ -1334,6 +1357,7 @@ double pe_diag_div_reciprocal(double b) { return div_const_reciprocal(b); }
 const char *pe_error_string(int code) {
     if (code == PE_ERR_BAD_CONFIG) return "pe_env: configuration outside kernel limits";
     if (code == PE_ERR_NULL) return "pe_env: null argument";
+    if (code == PE_ERR_RESET_FAILED) return "pe_env: a placement loop of the episode reset gave up after PE_RESET_MAX_DRAWS draws (map too crowded for this configuration)";
     return hipGetErrorString((hipError_t)code);
 }
 

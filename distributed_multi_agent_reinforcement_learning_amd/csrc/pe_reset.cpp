@@ -47,14 +47,18 @@ void inflate(int W, int H, uint8_t *g, int x, int y, int ext) {
             if (xx >= 0 && xx < W && yy >= 0 && yy < H) g[xx * H + yy] = 1;
 }
 
-void draw_target(int W, int H, const uint8_t *infl, PyRandom &py, int32_t *out) {  // base_env.py:52-70
-    for (;;) {
+// base_env.py:52-70; false when PE_RESET_MAX_DRAWS candidates were all occupied (the last one is kept)
+bool draw_target(int W, int H, const uint8_t *infl, PyRandom &py, int32_t *out) {
+    for (int draws = 0; draws < PE_RESET_MAX_DRAWS; draws++) {
         int tx = py.randint(0, W - 1), ty = py.randint(0, H - 1);
-        if (infl[tx * H + ty] == 0) { out[0] = tx; out[1] = ty; return; }
+        out[0] = tx; out[1] = ty;
+        if (infl[tx * H + ty] == 0) return true;
     }
+    return false;
 }
 
-void reset_one(Resetter &R, int n, int consumed, const pe_host_init_out &o) {
+// returns false when a placement loop gave up (PE_RESET_MAX_DRAWS); the arrays then hold the last candidates
+bool reset_one(Resetter &R, int n, int consumed, const pe_host_init_out &o) {
     const pe_config &c = R.cfg;
     const int W = c.W, H = c.H, WH = W * H, P = c.P, O = c.O;
     EnvRng &rg = R.rng[n];
@@ -65,6 +69,7 @@ void reset_one(Resetter &R, int n, int consumed, const pe_host_init_out &o) {
         int32_t tmp[2];
         for (int k = 0; k < consumed; k++) draw_target(W, H, infl_static, rg.py, tmp);
     }
+    bool all_ok = true;
     uint8_t *grid = o.grid + (size_t)n * WH;
     memset(grid, 0, WH);
     // init_map -> initailize_obstacle -> add_blocker_type('r', (6, 7)) : x, y in [-3, 3) (Occupied_Grid_Map.py:46-62)
@@ -98,14 +103,16 @@ void reset_one(Resetter &R, int n, int consumed, const pe_host_init_out &o) {
             }
         }
     o.n_obs[n] = n_obs;  // > O is reported to the caller (the reference's buffer would not fit it either)
-    draw_target(W, H, infl.data(), rg.py, o.target + 2 * n);
+    all_ok = draw_target(W, H, infl.data(), rg.py, o.target + 2 * n) && all_ok;
     // init_defender (base_env.py:72-120)
     double *def = o.def + (size_t)n * P * 4;
     std::vector<int> cells;
-    int placed = 0;
+    int placed = 0, draws = 0;
     while (placed < P) {
         double px = rg.np.random_sample() * (double)(W - 1), py = rg.np.random_sample() * (double)(H - 1);
         bool ok = false;
+        if (++draws > PE_RESET_MAX_DRAWS) { ok = true; all_ok = false; }  // give up: keep this candidate, flag the environment
+        else
         if (infl[py_round(px) * H + py_round(py)] == 0) {
             if (placed == 0) {
                 ok = true;
@@ -132,8 +139,14 @@ void reset_one(Resetter &R, int n, int consumed, const pe_host_init_out &o) {
     }
     // init_attacker (base_env.py:122-162), is_percepted=True
     double *eva = o.eva + (size_t)n * 4;
+    draws = 0;
     for (bool done = false; !done;) {
         double px = rg.np.random_sample() * (double)(W - 1), py = rg.np.random_sample() * (double)(H - 1);
+        if (++draws > PE_RESET_MAX_DRAWS) {
+            eva[0] = px; eva[1] = py; eva[2] = 0.0; eva[3] = 0.0;
+            all_ok = false;
+            break;
+        }
         if (infl[py_round(px) * H + py_round(py)] != 0) continue;
         for (size_t k = 0; k < cells.size(); k += 2)
             if (norm2((double)cells[k] - px, (double)cells[k + 1] - py) < c.def_sen_range) {
@@ -146,7 +159,8 @@ void reset_one(Resetter &R, int n, int consumed, const pe_host_init_out &o) {
     rg.py_before_tape = rg.py;
     rg.has_tape = true;
     int32_t *tape = o.tape + (size_t)n * c.tape_len * 2;
-    for (int k = 0; k < c.tape_len; k++) draw_target(W, H, infl_static, rg.py, tape + 2 * k);
+    for (int k = 0; k < c.tape_len; k++) all_ok = draw_target(W, H, infl_static, rg.py, tape + 2 * k) && all_ok;
+    return all_ok;
 }
 
 }  // namespace
@@ -198,8 +212,10 @@ int pe_resetter_reset(void *h, const int32_t *consumed_targets, const pe_host_in
     Resetter &R = *(Resetter *)h;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > R.N) n_threads = R.N;
+    std::vector<int> failed(n_threads, 0);  // one slot per thread: no shared writes
     auto work = [&](int t) {
-        for (int n = t; n < R.N; n += n_threads) reset_one(R, n, consumed_targets ? consumed_targets[n] : 0, *out);
+        for (int n = t; n < R.N; n += n_threads)
+            if (!reset_one(R, n, consumed_targets ? consumed_targets[n] : 0, *out)) failed[t] = 1;
     };
     if (n_threads == 1) {
         work(0);
@@ -208,6 +224,8 @@ int pe_resetter_reset(void *h, const int32_t *consumed_targets, const pe_host_in
         for (int t = 0; t < n_threads; t++) th.emplace_back(work, t);
         for (auto &x : th) x.join();
     }
+    for (int t = 0; t < n_threads; t++)
+        if (failed[t]) return PE_ERR_RESET_FAILED;
     return 0;
 }
 

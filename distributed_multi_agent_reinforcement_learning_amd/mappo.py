@@ -13,6 +13,7 @@ import torch
 
 from . import ops
 from .model import build_actor_critic
+from .pe_env import status_or, status_text
 
 BUFFER_KEYS = ("p_state", "e_state", "o_state", "p_adj", "e_adj", "o_adj", "actor_historical_embedding",
                "critic_historical_embedding", "v_n", "a_n", "a_logprob_n", "r", "active")
@@ -135,12 +136,12 @@ class MAPPO:
         rt = cfg.get("runtime", {})
         self.reference_quirks = bool(rt.get("reference_quirks", True))
         self.sample_seed = int(rt.get("seed", 0))
+        # position of this agent's action-sampling stream: rank r starts its Philox counter at r << 40, so data-parallel
+        # ranks (the reference's Workers are separate processes with independent torch generators, runner.py:81-86) draw
+        # independent exploration noise; rank 0 keeps the stream the single-process goldens were made with.  Set by the
+        # Trainer / Worker before the first rollout; the counter itself is part of the resume bundle.
+        self.sample_rank = int(rt.get("sample_rank", 0))
         self.use_graphs = bool(rt.get("use_graphs", True))
-        # update: critic branch on a second HIP stream.  Off by default: worth ~3 % on cfg2, but with DHGN depth > 0 (cfg3, 4096
-        # envs) the two branches' library GEMMs run concurrently and the update stops making progress (suspected: the BLAS
-        # handle's workspace / Stream-K flags are shared between the streams) -- our own kernels have no such shared state.
-        self.overlap_actor_critic = bool(rt.get("overlap_actor_critic", False))
-        self._side_stream = None
         self.last_adv = self.last_v_target = None
 
     # ---- update (:638-723) ------------------------------------------------------------------------------------
@@ -167,24 +168,11 @@ class MAPPO:
             # EmbeddingDataset2 (:95-113): hop k reads the stored embeddings of step t-1-k (clean per-net history)
             hist_a = [batch["actor_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
             hist_c = [batch["critic_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
-            # The actor and the critic branch share nothing but the encoder weights until the loss: the critic runs on a
-            # second stream (forward here, its backward nodes follow it there), which fills the CUs / MFMA slots the
-            # persistent GRU kernels (205 workgroups, serial over T) leave idle.
-            if self.overlap_actor_critic:
-                main = torch.cuda.current_stream()
-                if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream()
-                    warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-                    if warn_off is not None:
-                        warn_off(False)  # the shared encoder's AccumulateGrad nodes see both streams on purpose
-                self._side_stream.wait_stream(main)
-                with torch.cuda.stream(self._side_stream):
-                    values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
-                a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
-                main.wait_stream(self._side_stream)
-            else:
-                a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
-                values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
+            # One stream: running the critic branch beside the actor's on a second stream was tried in round 1 and removed --
+            # it put two library GEMMs in flight at once, and with DHGN depth > 0 at 4096 environments the update stopped making
+            # progress ("two-stream update").  A whole-device library GEMM is not a kernel to co-schedule.
+            a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
+            values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
             actor_loss, critic_loss = ops.ppo_loss(a_logprob_n_now, dist_entropy, values_now, batch["a_logprob_n"][n0:n1], adv[n0:n1],
                                                    batch["active"][n0:n1], batch["v_n"][n0:n1, :-1] if self.use_value_clip else None,
                                                    v_target[n0:n1], self.epsilon, self.entropy_coef, self.use_value_clip)
@@ -215,7 +203,12 @@ class MAPPO:
         sample_steps = 0
         for k in range(num_episode):
             ep_reward, ep_steps = self.run_episode(env, num_episode=k, actions_override=actions_override, init=init)
-            exp_reward += float(ep_reward.mean().item())
+            # one read-back per episode: the mean return and the kernels' status bits (tape exhausted / A* cap / path
+            # underflow silently break parity with the reference, so they are an error, not a statistic)
+            mean_r, bits = torch.stack((ep_reward.mean().double(), status_or(env.sim.meta).double())).tolist()
+            if bits:
+                raise RuntimeError("environment kernel status: " + status_text(int(bits)))
+            exp_reward += float(mean_r)
             sample_steps += ep_steps * N
         return exp_reward / num_episode, self.minibuffer, sample_steps
 
@@ -299,7 +292,7 @@ class _RolloutState:
         self.a_cur, self.c_cur = z(N, P, E), z(N, P, E)
         self.a_n = torch.zeros((N, P), dtype=torch.int32, device=dev)
         self.logp, self.v, self.raw = z(N, P), z(N, P), z(N, P)
-        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)   # position in the sampling stream (persists)
+        self.counter = torch.full((1,), int(agent.sample_rank) << 40, dtype=torch.int64, device=dev)  # position in the sampling stream (persists)
         self.graph = None
 
     def reset(self, env):

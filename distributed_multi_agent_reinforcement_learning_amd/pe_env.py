@@ -105,6 +105,23 @@ def load_library():
     return _lib
 
 
+STATUS_NAMES = ((1, "target tape exhausted (raise runtime.tape_len)"), (2, "A* iteration cap reached"),
+                (4, "stored path tail underflow (raise runtime.max_path)"),
+                (8, "episode reset gave up: no valid placement after PE_RESET_MAX_DRAWS draws (map too crowded for this configuration)"))
+
+
+def status_or(meta):
+    """bitwise OR over environments of meta[:, PE_META_STATUS] as a 0-d device tensor (no host sync)"""
+    st = meta[:, META_STATUS]
+    shifts = torch.arange(len(STATUS_NAMES), device=st.device, dtype=st.dtype)
+    flags = ((st[:, None] >> shifts) & 1).max(0).values
+    return (flags << shifts).sum()
+
+
+def status_text(bits):
+    return "; ".join(n for b, n in STATUS_NAMES if int(bits) & b)
+
+
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed: {load_library().pe_error_string(rc).decode()} (code {rc})")
@@ -389,7 +406,11 @@ class DeviceResetter:
                                        _ptr(sim.o_state), 1 if reset_reward_norm else 0, _stream()), "pe_env_reset")
         self.first = False
         sim.t_host = 0
-        worst = int(sim.n_obs.max().item())
+        # one blocking read-back per episode: the largest obstacle count and the sticky kernel status bits (pe_env.h: the
+        # finished episode's tape-exhausted / A*-cap / path-underflow bits are carried into the new meta record by the reset)
+        worst, bits = torch.stack((sim.n_obs.max(), status_or(sim.meta))).tolist()
+        if bits:
+            raise RuntimeError("environment kernel status: " + status_text(bits))
         if worst > self.c.O:
             raise ValueError(f"an environment has {worst} boundary obstacles > num_max_obstacle={self.c.O}")
 

@@ -81,11 +81,9 @@ class Pursuit_Env:
 
     def check_status(self):
         """Raises when a kernel flagged a condition that breaks parity with the reference (include/pe_env.h PE_STATUS_*)."""
-        bits = int(self.sim.meta[:, pe_env.META_STATUS].max().item()) if self.num_envs else 0
+        bits = int(pe_env.status_or(self.sim.meta).item()) if self.num_envs else 0
         if bits:
-            names = [n for b, n in ((1, "target tape exhausted (raise runtime.tape_len)"), (2, "A* iteration cap reached"),
-                                    (4, "stored path tail underflow (raise runtime.max_path)")) if bits & b]
-            raise RuntimeError("environment kernel status: " + "; ".join(names))
+            raise RuntimeError("environment kernel status: " + pe_env.status_text(bits))
 
     def _take_prefetched(self):
         pf = getattr(self, "_prefetch", None)

@@ -69,6 +69,7 @@ class Worker:
     def __init__(self, worker_id, cfg, num_envs=None):
         self.env = Pursuit_Env(cfg, num_envs=num_envs, rank=worker_id)
         self.agent = MAPPO(cfg, None, None, "Worker")
+        self.agent.sample_rank = int(worker_id)  # every reference Worker has its own torch generator (runner.py:81-86)
         self.sample_epi_num = cfg.algo.sample_epi_num
 
     def run(self, actor_weights, critic_weights):

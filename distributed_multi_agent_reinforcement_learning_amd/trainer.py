@@ -136,6 +136,7 @@ class Trainer:
         self.env = Pursuit_Env(cfg, num_envs=self.num_envs, rank=self.rank, device=self.device)
         torch.manual_seed(int(cfg.runtime.get("seed", 0)))
         self.agent = MAPPO(cfg, batch, self.mini_batch_size, "Learner")
+        self.agent.sample_rank = self.rank  # disjoint action-sampling streams per rank (mappo.MAPPO.sample_rank)
         broadcast_weights_([self.agent.actor, self.agent.critic])
         self.total_steps = 0
         self.iteration = 0

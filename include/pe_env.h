@@ -25,12 +25,21 @@ extern "C" {
 #define PE_META_INTS 8
 #define PE_ERR_BAD_CONFIG 10001
 #define PE_ERR_NULL 10002
+#define PE_ERR_RESET_FAILED 10003 /* a placement loop of Pursuit_Env.reset hit PE_RESET_MAX_DRAWS (see below) */
+/* The reference's reset uses unbounded rejection loops (base_env.py:52-70, 72-120, 122-162); on a map that admits no
+ * placement they never return.  Host resetter, device reset and the oracle all stop after this many draws per loop, flag
+ * the environment (PE_STATUS_RESET_FAILED / PE_ERR_RESET_FAILED) and keep the last candidate, so a bad configuration is an
+ * error instead of a hung launch.  Loops that terminate in the reference are unaffected (they need < 1e3 draws). */
+#define PE_RESET_MAX_DRAWS 100000
 
 /* meta[env][k] */
 enum { PE_META_T = 0, PE_META_PATH_LEN = 1, PE_META_TAPE_POS = 2, PE_META_COLLISION = 3, PE_META_PATH_CNT = 4,
        PE_META_ASTAR_EXP = 5, PE_META_STATUS = 6, PE_META_WP_HEAD = 7 /* waypoints popped since the last replan */ };
 /* meta[PE_META_STATUS] bits */
-enum { PE_STATUS_TAPE_EXHAUSTED = 1, PE_STATUS_ASTAR_CAP = 2, PE_STATUS_PATH_UNDERFLOW = 4 };
+enum { PE_STATUS_TAPE_EXHAUSTED = 1, PE_STATUS_ASTAR_CAP = 2, PE_STATUS_PATH_UNDERFLOW = 4, PE_STATUS_RESET_FAILED = 8 };
+/* The bits are STICKY on the device-reset path: pe_env_reset carries the finished episode's bits into the new episode's meta
+ * record, so one read of meta[:, PE_META_STATUS] after any reset (or at any later time) reports every condition raised since
+ * pe_env_reset_seed.  pe_env_load (host initial conditions) starts from 0. */
 
 /* Values of config.yaml (reference config.yaml:13-54) the kernels need.  Plain data, passed by value. */
 typedef struct pe_config {

@@ -117,7 +117,7 @@ def sequence_forward(sd, batch, hist_key, is_critic, depth, num_layers=2):
     E = emb.shape[-1]
     x = emb.permute(1, 0, 2, 3).reshape(T, N * P, E)
     H = sd["GRU.weight_hh_l0"].shape[1]
-    feat, _ = gru_apply(sd, x, torch.zeros(num_layers, N * P, H))
+    feat, _ = gru_apply(sd, x, torch.zeros(num_layers, N * P, H, dtype=x.dtype))
     feat = feat.reshape(T, N, P, H).permute(1, 0, 2, 3)
     if is_critic:
         return F.linear(feat, critic_head_weight(sd), sd["Mean.bias"]).squeeze(-1)
@@ -189,7 +189,7 @@ def ppo_losses(logp_now, entropy, values_now, batch, adv, v_target, epsilon, ent
     return actor_loss, critic_loss
 
 
-def train(sd_a, sd_c, batch, depth, mini_batch_size, gamma, lamda, epsilon, entropy_coef, clip=5.0):
+def train(sd_a, sd_c, batch, depth, mini_batch_size, gamma, lamda, epsilon, entropy_coef, clip=5.0, adv_override=None):
     """MAPPO.train (:638-723) on tensors that share storage for shared_net.* between sd_a and sd_c.
     Gradients accumulate over mini-batches with clip_grad_norm_ after every backward.
     Returns objC, objA, {name: grad} for the actor keys and for the critic keys, adv, v_target."""
@@ -209,6 +209,8 @@ def train(sd_a, sd_c, batch, depth, mini_batch_size, gamma, lamda, epsilon, entr
         t.grad = None
     with torch.no_grad():
         adv, v_target = gae(batch["r"], batch["v_n"], batch["active"], gamma, lamda)
+    if adv_override is not None:  # (adv, v_target) computed elsewhere, e.g. per data-parallel shard (main.py:105-129)
+        adv, v_target = adv_override
     N = batch["r"].shape[0]
     objC = objA = 0.0
     n_upd = 0

@@ -23,7 +23,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "n2n_oracle.c")):
             subprocess.check_call(["make", "-C", HERE, "libn2n_oracle.so"], stdout=subprocess.DEVNULL)
-        L = C.CDLL(LIB)
+        L = C.CDLL(os.environ.get("DMARL_N2N_ORACLE_LIB") or LIB)  # override: the sanitizer build (tools/sanitize_host.py)
         vp = C.c_void_p
         L.n2n_evader_step.argtypes = [vp, vp, vp]
         L.n2n_step.argtypes = [vp] * 8

@@ -36,7 +36,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("DMARL_PE_ORACLE_LIB") or LIB_PATH)  # override: the sanitizer build (tools/sanitize_host.py)
         vp = C.c_void_p
         L.peo_create.restype = vp
         L.peo_create.argtypes = [vp]

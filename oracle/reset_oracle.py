@@ -18,6 +18,12 @@ import random as _random
 
 import numpy as np
 
+MAX_DRAWS = 100000  # include/pe_env.h PE_RESET_MAX_DRAWS: the build's bound on the reference's unbounded rejection loops
+
+
+class ResetFailed(RuntimeError):
+    """a placement loop gave up after MAX_DRAWS candidates (the reference would loop forever)"""
+
 
 def inflate(grid, cells, ext):
     """Occupied_Grid_Map.py:157-166 / :126-135 -- stamp [-ext, ext]^2 around every cell, clipped by in_bound."""
@@ -42,10 +48,11 @@ def inner_boundary(grid):
 def draw_target(inflated, rnd=_random):
     """base_env.py:52-70"""
     W, H = inflated.shape
-    while True:
+    for _ in range(MAX_DRAWS):
         t = (rnd.randint(0, W - 1), rnd.randint(0, H - 1))
         if inflated[t] == 0:
             return t
+    raise ResetFailed("init_target")
 
 
 def reset_oracle(W, H, P, num_blocks, center, variance, comm_range=16, sen_range=8, min_dist=4, tape_len=0,
@@ -70,8 +77,12 @@ def reset_oracle(W, H, P, num_blocks, center, variance, comm_range=16, sen_range
     # init_defender (base_env.py:72-120)
     scale = np.array([W - 1, H - 1])
     positions, cells = [], []
+    draws = 0
     while len(positions) < P:
         pos = tuple(nprnd.rand(2) * scale)
+        draws += 1
+        if draws > MAX_DRAWS:
+            raise ResetFailed("init_defender")
         ok = False
         if inflated[round(pos[0]), round(pos[1])] == 0:
             if not positions:
@@ -90,8 +101,12 @@ def reset_oracle(W, H, P, num_blocks, center, variance, comm_range=16, sen_range
             inflate(inflated, cells, 2)
     # init_attacker (base_env.py:122-162), is_percepted=True
     evader = None
+    draws = 0
     while evader is None:
         pos = tuple(nprnd.rand(2) * scale)
+        draws += 1
+        if draws > MAX_DRAWS:
+            raise ResetFailed("init_attacker")
         if inflated[round(pos[0]), round(pos[1])] == 0:
             for block in cells:
                 if np.linalg.norm([block[0] - pos[0], block[1] - pos[1]]) < sen_range:

@@ -23,7 +23,7 @@ def _ac_parameters(actor, critic):
             + list(actor.Mean.parameters()))
 
 
-def _shard_grads(d, episodes):
+def _shard_grads(d, episodes, clip=5.0, adv_override=None):
     """per-learner gradients of the reference algorithm on a shard (own advantage normalisation), via the oracle"""
     from oracle import model_oracle as mo
     cfg, actor, critic = golden_models(d)
@@ -31,8 +31,20 @@ def _shard_grads(d, episodes):
     buf = {k: v[episodes] for k, v in buffer_tensors(d).items()}
     sd_a = {k: v.detach().clone() for k, v in actor.state_dict().items()}
     sd_c = {k: v.detach().clone() for k, v in critic.state_dict().items()}
-    _, _, ga, gc, _, _ = mo.train(sd_a, sd_c, buf, d["depth"], d["mb"], 0.99, 0.95, cfg.algo.epsilon, cfg.algo.entropy_coef)
+    _, _, ga, gc, _, _ = mo.train(sd_a, sd_c, buf, d["depth"], d["mb"], 0.99, 0.95, cfg.algo.epsilon, cfg.algo.entropy_coef, clip=clip,
+                                  adv_override=adv_override)
     return cfg, actor, critic, ga, gc
+
+
+def _flat_from_dicts(actor, critic, ga, gc):
+    """the Trainer's flat bucket (ac_parameters order) from the oracle's name -> gradient dicts"""
+    from distributed_multi_agent_reinforcement_learning_amd import trainer
+    for k, p in actor.named_parameters():
+        p.grad = ga[k].clone()
+    for k, p in critic.named_parameters():
+        if not k.startswith("shared_net."):
+            p.grad = gc[k].clone()
+    return trainer.flat_grads(_ac_parameters(actor, critic)).clone()
 
 
 def _worker(rank, world, port, q):
@@ -68,8 +80,25 @@ def _worker(rank, world, port, q):
     dist.all_gather(gathered, weights)
     gl = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gl, local)
+    # SURVEY 4 / main.py:105-129: the SUM over ranks of per-shard gradients (each shard with its OWN advantage normalisation,
+    # DHGN/mappo_parallel.py:655-658) equals ONE process differentiating the concatenated batch with those per-shard
+    # advantages.  Gradient clipping acts per learner before the sum (Q9), so it is disabled on both sides here: what is
+    # checked is the data-parallel decomposition itself (shards are whole mini-batches, so both sides see the same mini-batches).
+    from oracle import model_oracle as mo
+    _, a2, c2, ga2, gc2 = _shard_grads(d, shard, clip=1e30)
+    total2 = trainer.allreduce_sum_(_flat_from_dicts(a2, c2, ga2, gc2))
+    equiv = None
     if rank == 0:
-        q.put(dict(sum_ok=bool(torch.allclose(total, gl[0] + gl[1], rtol=0, atol=0)),
+        bt = buffer_tensors(d)
+        parts = [mo.gae(bt["r"][sh], bt["v_n"][sh], bt["active"][sh], 0.99, 0.95) for sh in ([0, 1], [2, 3])]
+        adv_cat = (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]))
+        _, a1, c1, ga1, gc1 = _shard_grads(d, [0, 1, 2, 3], clip=1e30, adv_override=adv_cat)
+        single = _flat_from_dicts(a1, c1, ga1, gc1)
+        whole_norm = _flat_from_dicts(*_shard_grads(d, [0, 1, 2, 3], clip=1e30)[1:])   # advantage normalisation over all 4: NOT the protocol
+        equiv = dict(err=float((total2 - single).abs().max()), scale=float(single.abs().max()),
+                     differs_from_global_norm=float((total2 - whole_norm).abs().max()))
+    if rank == 0:
+        q.put(dict(equiv=equiv, sum_ok=bool(torch.allclose(total, gl[0] + gl[1], rtol=0, atol=0)),
                    same_weights=bool(torch.equal(gathered[0], gathered[1])),
                    n=int(local.numel()), zeros=bool((after == 0).all()),
                    nonzero=float(total.abs().sum())))
@@ -90,6 +119,9 @@ def test_two_rank_gradient_sum_and_identical_update():
         assert p.exitcode == 0
     assert res["sum_ok"] and res["same_weights"] and res["zeros"] and res["nonzero"] > 0
     assert res["n"] == 125898 + 0 or res["n"] > 100000  # flat bucket of the E=64 depth-1 model
+    e = res["equiv"]
+    assert e["err"] <= 1e-5 * e["scale"], e                       # 2-rank sum == single process, per-shard advantage normalisation
+    assert e["differs_from_global_norm"] > 1e-3 * e["scale"], e    # ... and that is not what a global normalisation would give
 
 
 def test_allreduce_is_identity_on_one_rank():

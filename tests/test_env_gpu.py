@@ -303,3 +303,67 @@ def test_edge_configurations_match_oracle(P, W, H, blocks, variance):
             assert np.array_equal(r_n[n], oe.reward_norm(r).astype(np.float32)), (t, n)
             assert np.array_equal(defs[n], oe.state()["defenders"]), (t, n)
     assert not env.status().any().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", ["20x20_p4", "40x40_p8"])
+def test_device_reset_reproduces_reference_goldens(group):
+    """k_reset (Pursuit_Env.reset on the device, the default reset path) against the REFERENCE's own initial conditions:
+    a DeviceResetter seeded with the golden traces' seeds must produce their grid, boundary obstacles in index order,
+    first target, defender / evader positions (f64) and the target re-draw sequence bit for bit
+    (pursuit_env.py:60-73, base_env.py:37-162; fixtures made by tests/golden/gen/make_goldens_env.py)."""
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from distributed_multi_agent_reinforcement_learning_amd import pe_env
+    traces = [load_trace(p) for p in trace_files(f"env_trace_{group}_*.npz")]
+    d0 = traces[0]
+    cfg = product_cfg(d0["P"], d0["W"], d0["H"], T=d0["T"], blocks=d0["blocks"], variance=d0["variance"],
+                      **{"runtime.device_reset": True})
+    seeds = [d["seed"] for d in traces]
+    env = Pursuit_Env(cfg, num_envs=len(traces), seeds=seeds)
+    assert isinstance(env.resetter, pe_env.DeviceResetter)
+    env.reset()
+    sim = env.sim
+    grid = sim.grid.cpu().numpy().reshape(len(traces), d0["W"], d0["H"])
+    bidx = sim.bidx.cpu().numpy().reshape(len(traces), d0["W"], d0["H"])
+    n_obs = sim.n_obs.cpu().numpy(); tgt = sim.target.cpu().numpy(); tape = sim.tape.cpu().numpy()
+    defs = sim.defenders_aos().cpu().numpy(); eva = sim.eva.cpu().numpy(); o_state = sim.o_state.cpu().numpy()
+    for n, d in enumerate(traces):
+        k = int(d["n_obs"])
+        assert np.array_equal(grid[n], d["grid"]), n
+        assert n_obs[n] == k, n
+        assert np.array_equal(o_state[n, :k, :2], d["obs_xy"].astype(np.float32)) and not o_state[n, k:].any() and not o_state[n, :, 2:].any(), n
+        want_bidx = np.full((d0["W"], d0["H"]), -1, np.int16)
+        want_bidx[d["obs_xy"][:, 0], d["obs_xy"][:, 1]] = np.arange(k)
+        assert np.array_equal(bidx[n], want_bidx), n
+        assert np.array_equal(tgt[n], d["target0"]), n
+        assert np.array_equal(defs[n, :, :2], d["defenders0"][:, :2]) and not defs[n, :, 2:].any(), n
+        assert np.array_equal(eva[n, :2], d["evader0"][:2]) and not eva[n, 2:].any(), n
+        nt = min(len(d["tape"]), tape.shape[1])
+        assert np.array_equal(tape[n, :nt], d["tape"][:nt]), n
+
+
+@pytest.mark.gpu
+def test_lidar_full_map_sweep_matches_reference_raser_maps():
+    """E6: the HIP LiDAR evaluated from EVERY cell of the three maps whose full raser table the reference produced
+    (get_raser_map, pursuit_env.py:29-53; fixtures env_trace_*_s0/_s2 `raser`): defenders are parked on all W*H cells
+    (P cells per environment, all environments share the map), one observe launch, rows must equal raser[x][y] bit for bit."""
+    with_raser = [d for d in (load_trace(p) for p in trace_files()) if "raser" in d]
+    assert len(with_raser) == 3
+    for d in with_raser:
+        P, W, H, T, k = d["P"], d["W"], d["H"], d["T"], int(d["n_obs"])
+        N = (W * H + P - 1) // P
+        cfg = product_cfg(P, W, H, T, blocks=d["blocks"], variance=d["variance"])
+        env = _env(cfg, N)
+        init = init_from_traces([d] * N)
+        cells = np.arange(N * P) % (W * H)
+        frac = np.random.default_rng(1).uniform(0.0, 0.999, (N * P, 2))          # anywhere inside the cell: int() truncates
+        xy = np.stack((cells // H, cells % H), 1) + frac
+        init["defenders"][:, :, :2] = xy.reshape(N, P, 2)
+        env.load(init, reset_reward_norm=True)
+        obs = env.new_obs()
+        for rep in range(2):                                                        # second launch: served from the LiDAR cache
+            env.observe(obs)
+            oa = obs["o_adj"].cpu().numpy().reshape(N * P, -1)
+            want = d["raser"].reshape(W * H, k)[cells].astype(np.float32)
+            assert np.array_equal(oa[:, :k], want), (d["seed"], rep, int((oa[:, :k] != want).sum()))
+            assert not oa[:, k:].any()

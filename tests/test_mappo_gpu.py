@@ -186,3 +186,70 @@ def test_rollout_and_update_run_on_other_shapes(depth, P, W, H):
     agent.ac_optimizer.step()
     assert not torch.equal(before, agent.actor.GRU.weight_hh_l0)
     assert len([k for k in agent.actor.state_dict() if "fcra" in k.lower()]) == 4 * depth
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_greedy_evaluate_full_length_episodes_bit_exact(name):
+    """north star: bit-exact greedy action indices -- at the real episode length.  Three T = 150 episodes per model
+    captured from the reference's evaluator.evaluate (evaluator.py:106-201) by tests/golden/gen/make_goldens_eval_grads.py on the
+    fixture's (sharpened) initial actor; the HIP path must reproduce every one of the 150 x P action indices and the return."""
+    from distributed_multi_agent_reinforcement_learning_amd.evaluator import evaluate
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    import os
+    from tests.helpers import GOLDEN
+    d = load_model_golden(name)
+    z = np.load(os.path.join(GOLDEN, f"eval150_{name}.npz"))
+    T, n = [int(v) for v in z["meta"]]
+    assert T == 150 and n >= 3
+    cfg, agent = make_agent(d, "Evaluator", **{"env.max_steps": T})
+    sharpen(d, agent.actor)
+    seeds = [int(s) for s in z["seeds"]]
+    pre = [f"s{s}_" for s in seeds]
+    init = dict(grid=np.stack([z[p + "grid"] for p in pre]), obs_xy=np.stack([z[p + "obs_xy"] for p in pre]),
+                n_obs=np.asarray([z[p + "n_obs"] for p in pre], np.int32), defenders=np.stack([z[p + "defenders"] for p in pre]),
+                evader=np.stack([z[p + "evader"] for p in pre]), target=np.stack([z[p + "target"] for p in pre]),
+                tape=np.stack([z[p + "tape"] for p in pre]))
+    env = Pursuit_Env(cfg, num_envs=n)
+    with torch.no_grad():
+        R, last, acts = evaluate(env, agent.actor, cfg, init=init, return_actions=True)
+    assert last == T - 1
+    acts = acts.cpu().numpy()
+    for k, p in enumerate(pre):
+        want = z[p + "actions"].astype(np.int64)
+        bad = np.argwhere(acts[k] != want)
+        assert bad.size == 0, (p, "first mismatch at (t, agent)", bad[0], len(bad))
+        assert abs(float(R[k]) - float(z[p + "return"])) < 1e-6
+        assert int(z[p + "last_index"]) == T - 1
+    assert not env.sim.status().any().item()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_train_full_gradient_tensors(name):
+    """Every gradient tensor of MAPPO.train (DHGN/mappo_parallel.py:660-723), element by element, against the reference's
+    (fixture grads_<name>.npz).  Tolerance per tensor from an fp64 run of oracle/model_oracle.py on the same buffer
+    (made by the generator): `noise` = max |reference fp32 - fp64| is the reference's own rounding noise for that tensor;
+    two fp32 evaluations with different summation orders differ by about the sum of their noises, so the bound is
+    GRAD_NOISE_FACTOR x noise + GRAD_REL_FLOOR x max|g|."""
+    import os
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import ReplayBuffer
+    from tests.helpers import GOLDEN
+    GRAD_NOISE_FACTOR, GRAD_REL_FLOOR = 4.0, 2e-5
+    d = load_model_golden(name)
+    z = np.load(os.path.join(GOLDEN, f"grads_{name}.npz"))
+    cfg, agent = make_agent(d, "Learner")
+    sharpen(d, agent.actor)
+    rb = ReplayBuffer.from_tensors(cfg, buffer_tensors(d), d["init_n_obs"], agent.device)
+    objC, objA, ag, cg = agent.train(rb, int(d["steps"]))
+    assert abs(objC - float(z["objC"])) <= 1e-4 * (1 + abs(float(z["objC"]))) and abs(objA - float(z["objA"])) <= 1e-4 * (1 + abs(float(z["objA"])))
+    worst = (0.0, None)
+    for who, grads, names, m in (("a", ag, z["actor_names"], agent.actor), ("c", cg, z["critic_names"], agent.critic)):
+        assert [n for n, _ in m.named_parameters()] == [str(n) for n in names]
+        for n, g in zip(names, grads):
+            n = str(n)
+            ref, noise, scale = z[f"{who}grad_{n}"], float(z[f"{who}noise_{n}"]), float(z[f"{who}scale_{n}"])
+            err = float(np.max(np.abs(np.asarray(g, np.float64) - ref)))
+            tol = GRAD_NOISE_FACTOR * noise + GRAD_REL_FLOOR * scale
+            if err / tol > worst[0]:
+                worst = (err / tol, f"{who}:{n} err {err:.3e} noise {noise:.3e} scale {scale:.3e}")
+            assert err <= tol, (who, n, err, tol, noise, scale)
+    print("worst gradient error / tolerance:", worst)

@@ -69,19 +69,25 @@ def test_training_loop_checkpoints_and_recorder(tmp_path):
 
 
 def test_two_rank_bench_rehearsal(tmp_path):
-    """bench.py under torch.distributed.run with 2 ranks sharing the one GPU (gloo stands in for RCCL): the N > 1 path
-    -- shard seeds per rank, gradient all-reduce, max-over-ranks timing, one JSON line from rank 0 -- runs end to end."""
+    """`python bench.py --gpus 2` -- the driver's own command form -- starts its two ranks itself (torch.distributed.run child)
+    before touching the GPU; here both ranks share the one GPU, so gloo stands in for RCCL.  The N > 1 path -- shard seeds per
+    rank, gradient all-reduce, max-over-ranks timing, one JSON line from rank 0 -- runs end to end."""
     env = dict(os.environ, DMARL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "cfg1",
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "cfg1",
            "--num-envs", "16", "--max-steps", "12", "--tick-samples", "12"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and "gloo" in j["config"]["collective"]
     assert abs(j["value"] - 2 * 16 * 12 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+    # a launcher whose world size contradicts --gpus is an error, not silently ignored
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "disagrees" in (bad.stderr + bad.stdout)
 
 
 def test_prefetched_reset_equals_inline_reset(tmp_path):
@@ -147,3 +153,65 @@ def test_empty_map_trains(tmp_path, device_reset):
     assert all(torch.isfinite(p).all() for p in tr.agent.ac_parameters)
     assert any(not torch.equal(p.detach(), b) for p, b in zip(tr.agent.ac_parameters, before))
     tr.env.check_status()
+
+
+def test_default_loop_reports_kernel_status_bits(tmp_path):
+    """with the default on-device reset nothing used to read the kernels' status bits.  A one-entry target tape is
+    exhausted within an episode on a 20 x 20 map; the production loop (Trainer.iterate) must raise, not train on."""
+    from distributed_multi_agent_reinforcement_learning_amd.trainer import Trainer
+    cfg = small_cfg(tmp_path, **{"runtime.tape_len": 1, "env.max_steps": 150, "runtime.num_envs": 64, "runtime.device_reset": True})
+    tr = Trainer(cfg)
+    with pytest.raises(RuntimeError, match="tape exhausted"):
+        for _ in range(3):
+            tr.iterate()
+
+
+def test_status_bits_survive_the_device_reset(tmp_path):
+    """the bits are sticky across pe_env_reset (k_reset carries them into the new meta record), so a caller that drives the
+    environment by hand and only looks after the next reset still sees them"""
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    cfg = small_cfg(tmp_path, **{"runtime.tape_len": 1, "env.max_steps": 150, "runtime.device_reset": True})
+    env = Pursuit_Env(cfg, num_envs=32)
+    env.reset()
+    obs = env.observe(); env.attacker_step()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(149):
+        env.tick(torch.randint(0, 9, (32, 4), generator=g, device="cuda", dtype=torch.int32), obs, torch.zeros(32, 4, device="cuda"))
+    assert int(env.sim.status().max()) & 1
+    with pytest.raises(RuntimeError, match="tape exhausted"):
+        env.reset()
+    assert int(env.sim.status().max()) & 1            # still there in the fresh episode's meta record
+
+
+@pytest.mark.timeout(120)
+def test_device_reset_reports_an_impossible_placement_instead_of_hanging(tmp_path):
+    """8 defenders on 12 x 31 with 8 blocks: the reference's placement loop never ends for some seeds; k_reset's loops are bounded
+    (PE_RESET_MAX_DRAWS, same bound as the host resetter and the oracle) and flag the environment."""
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    cfg = product_cfg(8, 12, 31, T=10, blocks=8, variance=3, **{"runtime.device_reset": True})
+    env = Pursuit_Env(cfg, num_envs=8, seeds=list(range(1000, 1008)))
+    with pytest.raises(RuntimeError, match="gave up"):
+        env.reset()
+    d = env.sim.defenders_aos()
+    assert bool(((d[..., 0] >= 0) & (d[..., 0] <= 11) & (d[..., 1] >= 0) & (d[..., 1] <= 30)).all())   # valid fallback state
+
+
+def test_ranks_draw_independent_exploration_noise(tmp_path):
+    """every data-parallel rank sampled actions from the same Philox stream.  Rank r now starts its counter at
+    r << 40: equal probabilities give different samples on different ranks, rank 0 keeps the stream of the goldens."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import MAPPO, _RolloutState
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    cfg = small_cfg(tmp_path)
+    env = Pursuit_Env(cfg, num_envs=8)
+    states = []
+    for r in (0, 1):
+        agent = MAPPO(cfg, 8, 4, "Learner")
+        agent.sample_rank = r
+        states.append(_RolloutState(agent, env))
+    assert int(states[0].counter.item()) == 0 and int(states[1].counter.item()) == 1 << 40
+    prob = torch.full((4096, 9), 1.0 / 9, device="cuda")
+    a0, _ = ops.categorical_sample(prob, 7, 0, counter=states[0].counter.clone())
+    a1, _ = ops.categorical_sample(prob, 7, 0, counter=states[1].counter.clone())
+    legacy, _ = ops.categorical_sample(prob, 7, 0)
+    assert torch.equal(a0, legacy) and (a0 != a1).float().mean() > 0.8
