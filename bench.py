@@ -351,6 +351,13 @@ def main():
     if not launched and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
 
+    # The CPU baseline runs FIRST, while this process has not touched the GPU: its one-process-per-core workers are started from a
+    # clean parent (the GPU box allows only a few processes with the device open; a worker never opens it -- tools/probe_gpu_open.py).
+    cpu = None
+    if not args.no_cpu_baseline and world_env == 1:
+        T_cpu = min(args.max_steps or 150, 150)
+        cpu = cpu_baseline(args.config, T_cpu)
+
     import torch.distributed as dist
     from distributed_multi_agent_reinforcement_learning_amd.trainer import dist_env
     rank, local_rank, world = dist_env()
@@ -374,8 +381,8 @@ def main():
         }
         if second is not None:
             out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "workload")}}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.config, min(main_res["episode_steps"], 150))
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

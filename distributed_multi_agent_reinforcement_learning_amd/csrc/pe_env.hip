@@ -1,11 +1,12 @@
 // pe_env.hip -- batched pursuit-evasion environment for MI355X (gfx950 / CDNA4).  C ABI: include/pe_env.h.
 //
-// One 64-lane wavefront (= one workgroup) owns one environment.  The environment's record (occupancy grid,
-// boundary-index map, agent state) is contiguous in HBM, so every global access of the wave is coalesced by
-// construction; grid + boundary-index map + agent state are staged once per launch in LDS and all neighbour /
-// obstacle / line-of-sight / LiDAR / A* lookups run out of LDS.  Launches keep the block -> environment map
-// fixed (block b == environment b), and blocks b, b+8, ... share an XCD, so an environment's record stays in
-// the same XCD's L2 from tick to tick.
+// One 64-lane wavefront (= one workgroup) owns one environment.  The environment's record (occupancy grid, agent
+// state) is contiguous in HBM, so every global access of the wave is coalesced by construction; grid + agent state are
+// staged once per launch in LDS and all neighbour / obstacle / line-of-sight / A* lookups run out of LDS.  The LiDAR
+// row of a cell (pursuit_env.py:29-53 get_raser_map) is tabulated per episode by k_build_raser, bit-packed, and the tick
+// gathers the P rows of the defenders' cells.  Launches keep the block -> environment map fixed (block b ==
+// environment b), and blocks b, b+8, ... share an XCD, so an environment's record stays in the same XCD's L2 from tick
+// to tick.
 //
 // Numerics: environment state is f64.  Build with -ffp-contract=off: the only fused multiply-add is the
 // explicit one inside norm2(), which mirrors how numpy evaluates np.linalg.norm of a 2-vector in the
@@ -52,7 +53,10 @@ struct SqThr {
     double sen_le;      // sqrt(x) <= defender.sen_range
     double evacoll_le;  // sqrt(x) <= attacker.collision_radius
     double res_lt;      // sqrt(x) <  map.resolution
+    uint32_t o4_magic;  // floor(i / (O / 4)) == (i * o4_magic) >> 20 for every i < P * O / 4 (host-verified), 0 = divide
+    int32_t rw_shift;   // log2 of the raser row length in words when it is a power of two, else -1
 };
+__host__ __device__ inline int raser_row_words(int O) { return (((O + 31) >> 5) + 3) & ~3; }  // 16-byte aligned rows
 
 // One wave per workgroup: the lanes only ever exchange data with lanes of their own wave.  A wave's LDS and vector-memory
 // instructions execute in program order through the same LDS / L1, so a wavefront-scope fence (no s_waitcnt, no s_barrier)
@@ -111,11 +115,10 @@ __device__ __forceinline__ void wave_argmin_f(double &f, unsigned int &sel) {
 
 struct Lds {
     uint8_t *grid;   // [W*H]
-    int16_t *bidx;   // [W*H]
     double *def;     // [4][P]
     double *prop;    // [4][P]
     double *eva;     // [4]
-    uint8_t *oadj;   // [P*O]  LiDAR hit flags as bytes (4x less LDS than floats: 16 workgroups fit a CU, one round of waves)
+    uint32_t *rw;    // [P][raser_row_words(O)]  LiDAR rows (hit bits) of the defenders' cells
     uint8_t *cond;   // [P*P]
     int32_t *misc;   // [8 + 2*PE_MAX_P]: [8..] rounded defender cells (replan)
     // replan scratch
@@ -130,7 +133,6 @@ struct Lds {
     __device__ __forceinline__ int32_t *tg() const { return m + PE_META_INTS + PE_MAX_P; }
     __device__ __forceinline__ int32_t *tp() const { return m + PE_META_INTS + PE_MAX_P + 2; }
     __device__ __forceinline__ uint32_t *wp() const { return (uint32_t *)(m + PE_META_INTS + PE_MAX_P + 2 + 2 * PE_TAPE_LDS); }
-    uint32_t *lc;    // [P * (1 + ceil(O/32))]  LiDAR cache
     double *rnl;     // [1 + 2P]  reward normaliser
 };
 
@@ -145,13 +147,11 @@ __host__ __device__ inline size_t lds_layout(const pe_config &c, bool with_obs, 
     size_t o_def = take(sizeof(double) * 4 * P);
     size_t o_prop = take(sizeof(double) * 4 * P);
     size_t o_eva = take(sizeof(double) * 4);
-    size_t o_oadj = take(with_obs ? P * c.O : 0);
+    size_t o_rw = take(with_obs ? sizeof(uint32_t) * P * raser_row_words(c.O) : 0);
     size_t o_misc = take(sizeof(int32_t) * (8 + 2 * PE_MAX_P));
-    size_t o_bidx = take(sizeof(int16_t) * (with_obs ? WH : 0));
     size_t o_parent = take(sizeof(uint16_t) * (with_replan ? NN : 0));
     size_t o_olist = take(sizeof(uint16_t) * (with_replan ? NN : 0));
     size_t o_m = take(sizeof(int32_t) * (PE_META_INTS + PE_MAX_P + 2 + 2 * PE_TAPE_LDS + PE_WP_WINDOW));
-    size_t o_lc = take(sizeof(uint32_t) * (with_obs ? P * (1 + (c.O + 31) / 32) : 0));
     size_t o_grid = take(WH);
     size_t o_cond = take(P * P);
     size_t o_obs = take(with_replan ? NN : 0);
@@ -161,14 +161,12 @@ __host__ __device__ inline size_t lds_layout(const pe_config &c, bool with_obs, 
         l->def = (double *)(base + o_def);
         l->prop = (double *)(base + o_prop);
         l->eva = (double *)(base + o_eva);
-        l->oadj = base + o_oadj;
+        l->rw = (uint32_t *)(base + o_rw);
         l->misc = (int32_t *)(base + o_misc);
-        l->bidx = (int16_t *)(base + o_bidx);
         l->parent = (uint16_t *)(base + o_parent);
         l->olist = (uint16_t *)(base + o_olist);
         l->rnl = (double *)(base + o_rnl);
         l->m = (int32_t *)(base + o_m);
-        l->lc = (uint32_t *)(base + o_lc);
         l->grid = base + o_grid;
         l->cond = base + o_cond;
         l->obs = base + o_obs;
@@ -225,14 +223,22 @@ __device__ __forceinline__ void dynamic(double tau, double itau, double i6, doub
 __device__ __forceinline__ bool in_bound_i(const pe_config &c, int x, int y) { return x < c.W && x >= 0 && y < c.H && y >= 0; }
 
 // ---- defenders: Pursuit_Env.step + defender_reward + collision_detection (pursuit_env.py:104-177) ------
+// The reference scores the defenders one after the other and clips an accepted proposal IN PLACE before the next one is
+// scored against it.  The order only matters through accepted proposals that lie outside the clip box
+// [0, W-1] x [0, H-1] (a defender pushing against the map border): for everybody else clipping is the identity.
+// FAST8 (P <= 8, lane = 8 i + j): every pair distance is evaluated once against the unclipped AND the clipped proposal of j,
+// every probe of every defender in two wave instructions; the in-place semantics are then resolved on 64-bit wave masks --
+// for the (rare) out-of-box defenders b in index order: accepted(b) swaps column b of the pair mask to the clipped
+// distances for the rows behind it.  Exactly the reference's sequential result, without the P-iteration loop.
+template <bool FAST8>
 __device__ void dev_step(const pe_config &c, const SqThr &th, const Lds &l, int lane, double *def_hbm, const pe_step_out &out, int env) {
     const int P = c.P;
     int32_t *meta = l.m;
     double *rn = l.rnl;
+    double o[4] = {0.0, 0.0, 0.0, 0.0};
     if (lane < P) {
         int a = l.acts()[lane];
         a = a < 0 ? 0 : (a > 8 ? 8 : a);
-        double o[4];
         dynamic(c.def_tau, th.inv_def_tau, th.inv_six, c.def_dt, l.def[lane], l.def[P + lane], l.def[2 * P + lane], l.def[3 * P + lane], c.action_u[a][0],
                 c.action_u[a][1], o);
         l.prop[lane] = o[0]; l.prop[P + lane] = o[1]; l.prop[2 * P + lane] = o[2]; l.prop[3 * P + lane] = o[3];
@@ -240,41 +246,94 @@ __device__ void dev_step(const pe_config &c, const SqThr &th, const Lds &l, int 
     wave_sync();
     const double r = c.def_collision_radius;
     const double ex = l.eva[0], ey = l.eva[1];
+    const double wmax = (double)(c.W - 1), hmax = (double)(c.H - 1);
     int my_rew = 0, my_ok = 0, any_coll = 0;
-    for (int i = 0; i < P; i++) {  // sequential in the agent index: proposals are clipped in place
-        const double sx = l.prop[i], sy = l.prop[P + i];
-        // inner collisions against the current (possibly already clipped) proposals, self included
-        bool near = (lane < P) && (norm2sq(l.prop[lane] - sx, l.prop[P + lane] - sy) <= th.coll_le);
-        int cnt = __popcll(__ballot(near));
-        // 3x3 probe of the static map at half-radius offsets; only in-bound probes count (pursuit_env.py:152-163)
-        bool hit = false;
-        if (lane < 9) {
-            int a = lane / 3 - 1, b = lane % 3 - 1;
-            double qx = sx + (double)a * r, qy = sy + (double)b * r;
-            int ix = py_round(qx), iy = py_round(qy);
-            if (in_bound_i(c, ix, iy)) hit = l.grid[ix * c.H + iy] != 0;
+    if (FAST8) {
+        const int i = lane >> 3, j = lane & 7;
+        const bool iv = i < P, pv = iv && j < P;
+        const double xi = l.prop[iv ? i : 0], yi = l.prop[P + (iv ? i : 0)];
+        const double xj = l.prop[pv ? j : 0], yj = l.prop[P + (pv ? j : 0)];
+        const double cxj = xj < 0.0 ? 0.0 : (xj > wmax ? wmax : xj), cyj = yj < 0.0 ? 0.0 : (yj > hmax ? hmax : yj);
+        // inner collisions (pursuit_env.py:132-137): j against i's own (still unclipped) proposal, self included
+        const unsigned long long Mu = __ballot(pv && norm2sq(xj - xi, yj - yi) <= th.coll_le);
+        const unsigned long long Mc = __ballot(pv && norm2sq(cxj - xi, cyj - yi) <= th.coll_le);
+        const unsigned int outb = (unsigned int)(__ballot(pv && i == 0 && (cxj != xj || cyj != yj)) & 0xFFull);
+        // 3x3 probe of the static map at half-radius offsets; only in-bound probes count, any occupied one rejects
+        // (pursuit_env.py:152-163): probes 0..7 of defender i on lanes 8 i + k, probe 8 (offset (+r, +r)) on lanes 8 i
+        unsigned long long HA, HB;
+        {
+            const int a3 = (j * 11) >> 5;  // j / 3 for j < 8
+            const double qx = xi + (double)(a3 - 1) * r, qy = yi + (double)(j - 3 * a3 - 1) * r;
+            const int ix = py_round(qx), iy = py_round(qy);
+            HA = __ballot(iv && in_bound_i(c, ix, iy) && l.grid[ix * c.H + iy] != 0);  // all eight probes, whatever P is
+            const double q8x = xi + r, q8y = yi + r;  // (double)1 * r == r
+            const int jx = py_round(q8x), jy = py_round(q8y);
+            HB = __ballot(iv && j == 0 && in_bound_i(c, jx, jy) && l.grid[jx * c.H + jy] != 0);
         }
-        int col = __ballot(hit) != 0ull;
-        int rew = -(cnt - 1) - col;
-        int ok = 0;
-        if (rew < 0) {
-            any_coll = 1;
-        } else {
-            double cx = sx < 0.0 ? 0.0 : (sx > (double)(c.W - 1) ? (double)(c.W - 1) : sx);
-            double cy = sy < 0.0 ? 0.0 : (sy > (double)(c.H - 1) ? (double)(c.H - 1) : sy);
-            if (lane == 0) { l.prop[i] = cx; l.prop[P + i] = cy; }
-            if (norm2sq(ex - cx, ey - cy) <= th.coll_le) rew += 1;
-            ok = 1;
+        unsigned long long M = Mu;
+        for (unsigned int todo = outb; todo;) {  // wave-uniform; empty unless a proposal left the clip box
+            const int b = __ffs(todo) - 1;
+            todo &= todo - 1u;
+            const int cnt = __popcll((M >> (8 * b)) & 0xFFull);
+            const bool col = (((HA >> (8 * b)) & 0xFFull) | ((HB >> (8 * b)) & 1ull)) != 0ull;
+            if (-(cnt - 1) - (col ? 1 : 0) >= 0 && b < 7) {  // accepted: later defenders are scored against its clipped position
+                const unsigned long long colmask = (0x0101010101010101ull << b) & (~0ull << (8 * (b + 1)));
+                M = (M & ~colmask) | (Mc & colmask);
+            }
         }
-        if (lane == i) { my_rew = rew; my_ok = ok; }
-        wave_sync();
-    }
-    if (lane < P) {
-        if (my_ok) {
+        double cx = 0.0, cy = 0.0;
+        if (lane < P) {
+            const int cnt = __popcll((M >> (8 * lane)) & 0xFFull);
+            const int col = ((((HA >> (8 * lane)) & 0xFFull) | ((HB >> (8 * lane)) & 1ull)) != 0ull) ? 1 : 0;
+            my_rew = -(cnt - 1) - col;
+            if (my_rew >= 0) {
+                cx = o[0] < 0.0 ? 0.0 : (o[0] > wmax ? wmax : o[0]);
+                cy = o[1] < 0.0 ? 0.0 : (o[1] > hmax ? hmax : o[1]);
+                if (norm2sq(ex - cx, ey - cy) <= th.coll_le) my_rew += 1;
+                my_ok = 1;
+            }
+        }
+        any_coll = __ballot(lane < P && !my_ok) != 0ull;
+        if (lane < P && my_ok) {
+            l.def[lane] = cx; l.def[P + lane] = cy; l.def[2 * P + lane] = o[2]; l.def[3 * P + lane] = o[3];
+            def_hbm[lane] = cx; def_hbm[P + lane] = cy; def_hbm[2 * P + lane] = o[2]; def_hbm[3 * P + lane] = o[3];
+        }
+    } else {
+        for (int i = 0; i < P; i++) {  // sequential in the agent index: proposals are clipped in place
+            const double sx = l.prop[i], sy = l.prop[P + i];
+            // inner collisions against the current (possibly already clipped) proposals, self included
+            bool near = (lane < P) && (norm2sq(l.prop[lane] - sx, l.prop[P + lane] - sy) <= th.coll_le);
+            int cnt = __popcll(__ballot(near));
+            // 3x3 probe of the static map at half-radius offsets; only in-bound probes count (pursuit_env.py:152-163)
+            bool hit = false;
+            if (lane < 9) {
+                int a = lane / 3 - 1, b = lane % 3 - 1;
+                double qx = sx + (double)a * r, qy = sy + (double)b * r;
+                int ix = py_round(qx), iy = py_round(qy);
+                if (in_bound_i(c, ix, iy)) hit = l.grid[ix * c.H + iy] != 0;
+            }
+            int col = __ballot(hit) != 0ull;
+            int rew = -(cnt - 1) - col;
+            int ok = 0;
+            if (rew < 0) {
+                any_coll = 1;
+            } else {
+                double cx = sx < 0.0 ? 0.0 : (sx > wmax ? wmax : sx);
+                double cy = sy < 0.0 ? 0.0 : (sy > hmax ? hmax : sy);
+                if (lane == 0) { l.prop[i] = cx; l.prop[P + i] = cy; }
+                if (norm2sq(ex - cx, ey - cy) <= th.coll_le) rew += 1;
+                ok = 1;
+            }
+            if (lane == i) { my_rew = rew; my_ok = ok; }
+            wave_sync();
+        }
+        if (lane < P && my_ok) {
             double nx = l.prop[lane], ny = l.prop[P + lane], nvx = l.prop[2 * P + lane], nvy = l.prop[3 * P + lane];
             l.def[lane] = nx; l.def[P + lane] = ny; l.def[2 * P + lane] = nvx; l.def[3 * P + lane] = nvy;
             def_hbm[lane] = nx; def_hbm[P + lane] = ny; def_hbm[2 * P + lane] = nvx; def_hbm[3 * P + lane] = nvy;
         }
+    }
+    if (lane < P) {
         // DHGN/normalization.py:12-35 : per-environment running mean/std of the reward vector
         double x = (double)my_rew, outv = x;
         if (c.use_reward_norm) {
@@ -309,42 +368,34 @@ __device__ void dev_step(const pe_config &c, const SqThr &th, const Lds &l, int 
 }
 
 // ---- observations: get_state, communicate, sensor (base_env.py:198-209, pursuit_env.py:182-209) --------
-__device__ void dev_observe(const pe_config &c, const SqThr &th, const Lds &l, int lane, int env, const pe_obs_out &o, int n_obs, uint32_t *lcache_hbm) {
-    uint32_t *lcache = l.lc;
-    const int P = c.P, O = c.O;
+// o_adj[i] = raser_map[int(x_i)][int(y_i)] (pursuit_env.py:201): the P rows of the episode's bit-packed raser table
+// (k_build_raser) are gathered with ONE global load issued up front and expanded to the fp32 rows the policy reads.
+template <bool FAST8>
+__device__ void dev_observe(const pe_config &c, const SqThr &th, const Lds &l, int lane, int env, const pe_obs_out &o, const uint32_t *raser_env) {
+    const int P = c.P, O = c.O, RW = raser_row_words(O);
+    uint32_t r_row = 0u;
+    const bool one_load = P * RW <= WAVE;
+    if (o.o_adj && one_load && lane < P * RW) {
+        const int i = th.rw_shift >= 0 ? lane >> th.rw_shift : lane / RW, w = lane - i * RW;
+        const int cell = (int)l.def[i] * c.H + (int)l.def[P + i];
+        r_row = raser_env[(size_t)cell * RW + w];  // in flight during the adjacency / line-of-sight work below
+    }
     if (o.p_state && lane < 4 * P) o.p_state[(int64_t)env * o.p_state_stride + lane] = (float)l.def[(lane & 3) * P + (lane >> 2)];
     if (o.e_state && lane < 4) o.e_state[(int64_t)env * o.e_state_stride + lane] = (float)l.eva[lane];
-    // communicate(): upper-triangular range test plus the adj[j, 1] = 1 side effect
-    if (P * P <= WAVE) {
-        // one pair per lane; the in-range bits stay in a 64-bit wave mask (no LDS round trip for the column-1 rule)
-        const int i = lane / P, j = lane - i * P;
-        const bool in_rng = lane < P * P && (i <= j) && (norm2sq(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= th.comm_le);
-        const unsigned long long cm = __ballot(in_rng);
-        for (int idx = lane; idx < (P * O) >> 2; idx += WAVE) ((uint32_t *)l.oadj)[idx] = 0u;  // O is a multiple of 4
-        if (o.p_adj && lane < P * P) {
-            bool v = in_rng;
-            if (j == 1) {  // adj[i, 1] is set whenever some row k <= i is in range of i (k == i always is)
-                unsigned long long col = 0ull;
-                for (int k = 0; k <= i; k++) col |= 1ull << (k * P + i);
-                v = v || ((cm & col) != 0ull);
+    // communicate(): upper-triangular range test; `adj[j, 1] = 1` fires for every row j through the pair (j, j), whose
+    // distance is 0 -- column 1 is all ones whenever comm_range >= 0
+    const bool col1 = th.comm_le >= 0.0;
+    if (o.p_adj) {
+        if (FAST8) {
+            const int i = lane >> 3, j = lane & 7;
+            if (i < P && j < P) {
+                const bool v = ((i <= j) && (norm2sq(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= th.comm_le)) || (j == 1 && col1);
+                o.p_adj[(int64_t)env * o.p_adj_stride + i * P + j] = v ? 1.f : 0.f;
             }
-            o.p_adj[(int64_t)env * o.p_adj_stride + lane] = v ? 1.f : 0.f;
-        }
-        wave_sync();
-    } else {
-        for (int idx = lane; idx < P * P; idx += WAVE) {
-            int i = idx / P, j = idx - i * P;
-            l.cond[idx] = (i <= j) && (norm2sq(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= th.comm_le);
-        }
-        for (int idx = lane; idx < (P * O) >> 2; idx += WAVE) ((uint32_t *)l.oadj)[idx] = 0u;  // O is a multiple of 4
-        wave_sync();
-        if (o.p_adj) {
+        } else {
             for (int idx = lane; idx < P * P; idx += WAVE) {
-                int i = idx / P, j = idx - i * P;
-                bool v = l.cond[idx] != 0;
-                if (j == 1) {  // adj[i, 1] is set whenever some row k <= i is in range of i (k == i always is)
-                    for (int k = 0; k <= i; k++) v = v || (l.cond[k * P + i] != 0);
-                }
+                const int i = idx / P, j = idx - i * P;
+                const bool v = ((i <= j) && (norm2sq(l.def[i] - l.def[j], l.def[P + i] - l.def[P + j]) <= th.comm_le)) || (j == 1 && col1);
                 o.p_adj[(int64_t)env * o.p_adj_stride + idx] = v ? 1.f : 0.f;
             }
         }
@@ -369,93 +420,31 @@ __device__ void dev_observe(const pe_config &c, const SqThr &th, const Lds &l, i
         }
         o.e_adj[(int64_t)env * o.e_adj_stride + lane] = seen;
     }
-    // LiDAR from the truncated cell of every defender (pursuit_env.py:29-53, :201): beams x ranges out of LDS.
-    // The row depends on the cell only (the reference tabulates it per cell at reset), and a defender needs >= 5 ticks to
-    // leave a cell, so each defender keeps (cell, hit bits) in its record: an unchanged cell expands the cached bits, only
-    // the defenders that changed cell walk their 36 beams.  The kernel is instruction-bound, this removes ~80 % of the
-    // LiDAR instructions; results are identical by construction.
     if (o.o_adj) {
-        const int OW = (O + 31) >> 5, CW = 1 + OW;  // words per defender in the cache
-        uint32_t mycell = 0u;
-        bool changed = false;
-        if (lane < P) {
-            mycell = ((uint32_t)(int)l.def[lane] << 16) | (uint32_t)(int)l.def[P + lane];
-            changed = lcache[lane * CW] != mycell;
-        }
-        const unsigned long long chg = __ballot(changed);
-        // cached bits -> flag bytes, four obstacles (one LDS word) per lane and iteration; O is a multiple of 4, so a word
-        // never straddles two defenders
-        for (int wd = lane; wd < (P * O) >> 2; wd += WAVE) {
-            const int i = (4 * wd) / O, j = 4 * wd - i * O;
-            if ((chg >> i) & 1ull) continue;
-            const uint32_t nib = (lcache[i * CW + 1 + (j >> 5)] >> (j & 31)) & 0xFu;
-            ((uint32_t *)l.oadj)[wd] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
-        }
-        const int n_chg = __popcll(chg);
-        const int tasks = n_chg * c.num_beams;
-        for (int task = lane; task < tasks; task += WAVE) {
-            const int a = task / c.num_beams, b = task - a * c.num_beams;
-            unsigned long long m = chg;  // index of the a-th defender that changed cell
-            for (int k = 0; k < a; k++) m &= m - 1ull;
-            const int i = __ffsll((long long)m) - 1;
-            int cx = (int)l.def[i], cy = (int)l.def[P + i];
-            double bx = c.beam_dir[b][0], by = c.beam_dir[b][1];
-            if (c.lidar_radius <= 8) {
-                // all range samples of the beam are looked up at once (independent LDS reads in flight together: the kernel
-                // is latency-bound), then the first sample that leaves the map or hits a boundary cell decides
-                int ids[8];
-                bool oob[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const double px = (double)cx + (double)r * bx, py = (double)cy + (double)r * by;
-                    oob[r] = (r >= c.lidar_radius) || px < 0 || px >= (double)c.W || py < 0 || py >= (double)c.H;
-                    ids[r] = l.bidx[oob[r] ? 0 : (int)px * c.H + (int)py];
-                }
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    if (oob[r]) break;
-                    if (ids[r] >= 0) {
-                        if (ids[r] < O && ids[r] < n_obs) l.oadj[i * O + ids[r]] = 1;
-                        break;
-                    }
-                }
-            } else {
-                for (int r = 0; r < c.lidar_radius; r++) {
-                    double px = (double)cx + (double)r * bx;
-                    double py = (double)cy + (double)r * by;
-                    if (px < 0 || px >= (double)c.W || py < 0 || py >= (double)c.H) break;
-                    int id = l.bidx[(int)px * c.H + (int)py];
-                    if (id >= 0) {
-                        if (id < O && id < n_obs) l.oadj[i * O + id] = 1;
-                        break;
-                    }
-                }
+        if (one_load) {
+            if (lane < P * RW) l.rw[lane] = r_row;
+        } else {
+            for (int idx = lane; idx < P * RW; idx += WAVE) {
+                const int i = idx / RW, w = idx - i * RW;
+                l.rw[idx] = raser_env[(size_t)((int)l.def[i] * c.H + (int)l.def[P + i]) * RW + w];
             }
         }
         wave_sync();
-        for (int i = 0; i < P; i++) {  // refresh the cache of the defenders that moved to another cell
-            if (!((chg >> i) & 1ull)) continue;
-            for (int w0 = 0; w0 < OW; w0 += 2) {
-                const int j = (w0 << 5) + lane;
-                const unsigned long long bits = __ballot(j < O && l.oadj[i * O + j] != 0);
-                if (lane == 0) {
-                    lcache_hbm[i * CW + 1 + w0] = (uint32_t)bits;
-                    if (w0 + 1 < OW) lcache_hbm[i * CW + 2 + w0] = (uint32_t)(bits >> 32);
-                }
+        // hit bits -> fp32 rows, four obstacles (16 bytes) per lane and store: the P rows of O floats are contiguous
+        float *dst = o.o_adj + (int64_t)env * o.o_adj_stride;
+        const int o4 = O >> 2, n4 = P * o4;
+        if ((((uintptr_t)dst) & 15) == 0) {
+            for (int idx = lane; idx < n4; idx += WAVE) {
+                const int i = th.o4_magic ? (int)(((uint32_t)idx * th.o4_magic) >> 20) : idx / o4, j4 = idx - i * o4;
+                const uint32_t wd = l.rw[i * RW + (j4 >> 3)];
+                const int sh = (j4 & 7) << 2;
+                ((float4 *)dst)[idx] = make_float4((float)((wd >> sh) & 1u), (float)((wd >> (sh + 1)) & 1u), (float)((wd >> (sh + 2)) & 1u),
+                                                   (float)((wd >> (sh + 3)) & 1u));
             }
-        }
-        if (changed) lcache_hbm[lane * CW] = mycell;
-        wave_sync();
-        {   // bytes -> fp32 rows of o_adj, 16 B per lane per store
-            float *dst = o.o_adj + (int64_t)env * o.o_adj_stride;
-            const uint32_t *src = (const uint32_t *)l.oadj;
-            if ((((uintptr_t)dst) & 15) == 0) {
-                for (int i = lane; i < (P * O) >> 2; i += WAVE) {
-                    const uint32_t v = src[i];
-                    ((float4 *)dst)[i] = make_float4((float)(v & 0xFFu), (float)((v >> 8) & 0xFFu), (float)((v >> 16) & 0xFFu), (float)(v >> 24));
-                }
-            } else {
-                for (int i = lane; i < P * O; i += WAVE) dst[i] = (float)l.oadj[i];
+        } else {
+            for (int idx = lane; idx < P * O; idx += WAVE) {
+                const int i = idx / O, j = idx - i * O;
+                dst[idx] = (float)((l.rw[i * RW + (j >> 5)] >> (j & 31)) & 1u);
             }
         }
     }
@@ -730,7 +719,7 @@ __device__ void dev_evader(const pe_config &c, const SqThr &th, const Lds &l, in
     wave_sync();
 }
 
-template <bool STEP, bool OBS, bool EVA, bool REPLAN>
+template <bool STEP, bool OBS, bool EVA, bool REPLAN, bool FAST8>
 __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state st, const int32_t *actions, const pe_step_out sout,
                                                const pe_obs_out oout, const SqThr th) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -739,53 +728,41 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
     Lds l;
     lds_layout(c, OBS, EVA && REPLAN, smem, &l);
     const int WH = c.W * c.H, P = c.P;
-    const int CW = 1 + ((c.O + 31) >> 5);
     double *def_hbm = st.def + (size_t)env * 4 * P;
     double *eva_hbm = st.eva + (size_t)env * 4;
     int32_t *meta_hbm = st.meta + (size_t)env * PE_META_INTS;
     double *rn_hbm = st.rn + (size_t)env * (1 + 2 * P);
-    uint32_t *lc_hbm = st.lcache + (size_t)env * P * CW;
     uint32_t *wp_hbm = st.wpw + (size_t)env * PE_WP_WINDOW;
     int32_t *target_hbm = st.target + (size_t)env * 2;
     const int32_t *tape_hbm = st.tape + (size_t)env * c.tape_len * 2;
     // ---- ONE batch of global loads: every record this tick needs is requested before the first wait, so a wave pays the
-    // HBM/L2 latency once instead of once per phase (the kernel is latency-bound: ~3.8 k instructions in ~57 k cycles per wave)
+    // HBM/L2 latency once instead of once per phase
     const uint8_t *gsrc = st.grid + (size_t)env * WH;
-    const int16_t *bsrc = st.bidx + (size_t)env * WH;
     const bool wide = (WH & 15) == 0 && WH <= 4096;
-    const int ng = WH >> 4, nb = WH >> 3;
-    const uint4 *g4 = (const uint4 *)gsrc, *b4 = (const uint4 *)bsrc;
+    const int ng = WH >> 4;
+    const uint4 *g4 = (const uint4 *)gsrc;
     const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
     // named registers (not an array: an indexed array would live in scratch memory)
 #define PE_LDG(k) uint4 rg##k = z4; if (wide && lane + WAVE * k < ng) rg##k = g4[lane + WAVE * k];
-#define PE_LDB(k) uint4 rb##k = z4; if (OBS && wide && lane + WAVE * k < nb) rb##k = b4[lane + WAVE * k];
     PE_LDG(0) PE_LDG(1) PE_LDG(2) PE_LDG(3)
-    PE_LDB(0) PE_LDB(1) PE_LDB(2) PE_LDB(3) PE_LDB(4) PE_LDB(5) PE_LDB(6) PE_LDB(7)
 #undef PE_LDG
-#undef PE_LDB
     double r_def = 0.0, r_eva = 0.0, r_rn = 0.0;
-    int32_t r_meta = 0, r_act = 0, r_tg = 0, r_tp = 0, r_nobs = 0;
-    uint32_t r_wp = 0, r_lc = 0;
+    int32_t r_meta = 0, r_act = 0, r_tg = 0, r_tp = 0;
+    uint32_t r_wp = 0;
     if (lane < 4 * P) r_def = def_hbm[lane];
     if (lane < 4) r_eva = eva_hbm[lane];
     if (lane < PE_META_INTS) r_meta = meta_hbm[lane];
     if (lane < 2) r_tg = target_hbm[lane];
     if (STEP && lane < P) r_act = actions[(size_t)env * P + lane];
     if (STEP && lane < 1 + 2 * P) r_rn = rn_hbm[lane];
-    if (OBS && lane < P * CW) r_lc = lc_hbm[lane];
-    if (OBS) r_nobs = st.n_obs[env];
     if (EVA && lane < PE_WP_WINDOW) r_wp = wp_hbm[lane];
     if (EVA && lane < 2 * c.tape_len && lane < 2 * PE_TAPE_LDS) r_tp = tape_hbm[lane];
     if (wide) {
 #define PE_STG(k) if (lane + WAVE * k < ng) ((uint4 *)l.grid)[lane + WAVE * k] = rg##k;
-#define PE_STB(k) if (OBS && lane + WAVE * k < nb) ((uint4 *)l.bidx)[lane + WAVE * k] = rb##k;
         PE_STG(0) PE_STG(1) PE_STG(2) PE_STG(3)
-        PE_STB(0) PE_STB(1) PE_STB(2) PE_STB(3) PE_STB(4) PE_STB(5) PE_STB(6) PE_STB(7)
 #undef PE_STG
-#undef PE_STB
     } else {
         copy_in(l.grid, gsrc, WH, lane);
-        if (OBS) copy_in(l.bidx, bsrc, WH * 2, lane);
     }
     if (lane < 4 * P) l.def[lane] = r_def;
     if (lane < 4) l.eva[lane] = r_eva;
@@ -793,17 +770,60 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
     if (lane < 2) l.tg()[lane] = r_tg;
     if (STEP && lane < P) l.acts()[lane] = r_act;
     if (STEP && lane < 1 + 2 * P) l.rnl[lane] = r_rn;
-    if (OBS && lane < P * CW) l.lc[lane] = r_lc;
-    if (OBS && P * CW > WAVE) for (int i = WAVE + lane; i < P * CW; i += WAVE) l.lc[i] = lc_hbm[i];
     if (EVA && lane < PE_WP_WINDOW) l.wp()[lane] = r_wp;
     if (EVA && lane < 2 * c.tape_len && lane < 2 * PE_TAPE_LDS) l.tp()[lane] = r_tp;
     wave_sync();
-    if (STEP) dev_step(c, th, l, lane, def_hbm, sout, env);
-    if (OBS) dev_observe(c, th, l, lane, env, oout, r_nobs, lc_hbm);
+    if (STEP) dev_step<FAST8>(c, th, l, lane, def_hbm, sout, env);
+    if (OBS) dev_observe<FAST8>(c, th, l, lane, env, oout, st.raser + (size_t)env * WH * raser_row_words(c.O));
     if (EVA) dev_evader<REPLAN>(c, th, l, lane, st.path + (size_t)env * c.max_path * 2, wp_hbm, target_hbm, tape_hbm, eva_hbm);
-    // ---- write the small records back (def / eva / target / LiDAR cache were written where they changed)
+    // ---- write the small records back (def / eva / target were written where they changed)
     if ((STEP || EVA) && lane < PE_META_INTS) meta_hbm[lane] = l.m[lane];
     if (STEP && c.use_reward_norm && lane < 1 + 2 * P) rn_hbm[lane] = l.rnl[lane];
+}
+
+// ---- get_raser_map (pursuit_env.py:29-53): the LiDAR row of EVERY cell, once per episode -----------------------------------
+// raser[cell][k] = 1 iff one of the num_beams beams from (x, y) = cell hits boundary obstacle k first: samples at the integer
+// ranges r = 0 .. radius-1, px = x + r cos, py = y + r sin (separate f64 multiply and add, truncation toward zero), the beam
+// ends at the first sample outside the map or on a boundary cell.  Bit-packed rows of raser_row_words(O) words.
+// One wavefront per environment, lane = cell (64 cells per pass), beams in the (wave-uniform) outer loop.
+__global__ __launch_bounds__(WAVE) void k_build_raser(const pe_config c, const pe_state st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const int W = c.W, H = c.H, WH = W * H, O = c.O, RW = raser_row_words(O), RS = RW + 1;  // odd row stride: no bank conflicts
+    int16_t *bidx = (int16_t *)smem;
+    uint32_t *rows = (uint32_t *)(smem + align16(sizeof(int16_t) * WH));  // [WAVE][RS]
+    copy_in(bidx, st.bidx + (size_t)env * WH, WH * 2, lane);
+    const int n_obs = st.n_obs[env];
+    uint32_t *dst = st.raser + (size_t)env * WH * RW;
+    wave_sync();
+    for (int base = 0; base < WH; base += WAVE) {
+        const int cell = base + lane;
+        const bool live = cell < WH;
+        const int cx = live ? cell / H : 0, cy = live ? cell - cx * H : 0;
+        for (int w = 0; w < RW; w++) rows[lane * RS + w] = 0u;
+        for (int b = 0; b < c.num_beams; b++) {
+            const double bx = c.beam_dir[b][0], by = c.beam_dir[b][1];
+            bool going = live;
+            for (int r = 0; r < c.lidar_radius; r++) {
+                if (__ballot(going) == 0ull) break;  // wave-uniform
+                if (going) {
+                    const double px = (double)cx + (double)r * bx, py = (double)cy + (double)r * by;
+                    if (px < 0 || px >= (double)W || py < 0 || py >= (double)H) {
+                        going = false;
+                    } else {
+                        const int id = bidx[(int)px * H + (int)py];
+                        if (id >= 0) {
+                            if (id < O && id < n_obs) rows[lane * RS + (id >> 5)] |= 1u << (id & 31);
+                            going = false;
+                        }
+                    }
+                }
+            }
+        }
+        if (live)
+            for (int q = 0; q < RW; q += 4)
+                *(uint4 *)(dst + (size_t)cell * RW + q) = make_uint4(rows[lane * RS + q], rows[lane * RS + q + 1], rows[lane * RS + q + 2], rows[lane * RS + q + 3]);
+    }
 }
 
 // bidx from the obstacle list (pursuit_env.py:21: index == position in np.argwhere order)
@@ -824,7 +844,6 @@ __global__ void k_build_bidx(const pe_config c, const pe_state st, const int32_t
     if (threadIdx.x < PE_META_INTS)
         st.meta[(size_t)env * PE_META_INTS + threadIdx.x] = (threadIdx.x == PE_META_STATUS && rng) ? dev_rng_status(rng, env) : 0;
     if (threadIdx.x < PE_WP_WINDOW) st.wpw[(size_t)env * PE_WP_WINDOW + threadIdx.x] = 0u;
-    if (threadIdx.x < c.P) st.lcache[((size_t)env * c.P + threadIdx.x) * (1 + (c.O + 31) / 32)] = 0xFFFFFFFFu;  // empty LiDAR cache
 }
 
 // [N][P][4] (get_state order) -> [N][4][P] records
@@ -888,10 +907,19 @@ double div_const_reciprocal(double b) {
     return 1.0 / b;
 }
 
-template <bool STEP, bool OBS, bool EVA, bool REPLAN>
-int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
+// Host: M with floor(i / d) == (i * M) >> 20 for every 0 <= i < n, or 0 when no 32-bit product qualifies (checked exhaustively)
+uint32_t div_magic20(uint32_t d, uint32_t n) {
+    if (d == 0 || n == 0 || (uint64_t)n * ((1u << 20) / d + 1) >= (1ull << 32)) return 0;
+    const uint32_t M = ((1u << 20) + d - 1) / d;
+    for (uint32_t i = 0; i < n; i++)
+        if (((i * M) >> 20) != i / d) return 0;
+    return M;
+}
+
+template <bool STEP, bool OBS, bool EVA, bool REPLAN, bool FAST8>
+int launch2(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
     size_t lds = lds_layout(*cfg, OBS, EVA && REPLAN, nullptr, nullptr);
-    auto kern = k_tick<STEP, OBS, EVA, REPLAN>;
+    auto kern = k_tick<STEP, OBS, EVA, REPLAN, FAST8>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -909,10 +937,24 @@ int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, con
     th.sen_le = sq_threshold(cfg->def_sen_range, false);
     th.evacoll_le = sq_threshold(cfg->eva_collision_radius, false);
     th.res_lt = sq_threshold(cfg->resolution, true);
+    th.o4_magic = div_magic20((uint32_t)(cfg->O >> 2), (uint32_t)(cfg->P * (cfg->O >> 2)));
+    const int rw = raser_row_words(cfg->O);
+    th.rw_shift = -1;
+    for (int sft = 0; sft < 16; sft++)
+        if ((1 << sft) == rw) th.rw_shift = sft;
     hipLaunchKernelGGL(kern, dim3(st->N), dim3(WAVE), lds, (hipStream_t)stream, *cfg, *st, actions, so ? *so : s0, oo ? *oo : o0, th);
     return (int)hipGetLastError();
 }
 
+template <bool STEP, bool OBS, bool EVA, bool REPLAN>
+int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
+    if (OBS && !st->raser) return PE_ERR_NULL;
+    return cfg->P <= 8 ? launch2<STEP, OBS, EVA, REPLAN, true>(cfg, st, actions, so, oo, stream)
+                       : launch2<STEP, OBS, EVA, REPLAN, false>(cfg, st, actions, so, oo, stream);
+}
+
+// the per-episode tables derived from the grid and the obstacle list: bidx, fresh meta / waypoint records, raser rows
+int launch_episode_tables(const pe_config *cfg, const pe_state *st, const int32_t *d_obs, const void *rng, hipStream_t s);
 
 // ---- Pursuit_Env.reset on the device ---------------------------------------------------------------------
 // The host resetter (pe_reset.cpp) restated for one wavefront per environment: the same two generator streams (CPython
@@ -1198,6 +1240,18 @@ __global__ void k_reset_seed(int N, const uint64_t *seeds, DevRng *rng) {
     R.snap_idx = 624; R.has_gauss = 0; R.has_tape = 0; R.status = 0; R.gauss = 0.0;
 }
 
+int launch_episode_tables(const pe_config *cfg, const pe_state *st, const int32_t *d_obs, const void *rng, hipStream_t s) {
+    if (!st->raser) return PE_ERR_NULL;
+    hipLaunchKernelGGL(k_build_bidx, dim3(st->N), dim3(256), 0, s, *cfg, *st, d_obs, (const DevRng *)rng);
+    const size_t lds = align16(sizeof(int16_t) * cfg->W * cfg->H) + sizeof(uint32_t) * WAVE * (raser_row_words(cfg->O) + 1);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_build_raser, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_build_raser, dim3(st->N), dim3(WAVE), lds, s, *cfg, *st);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1211,6 +1265,7 @@ int pe_config_check(const pe_config *c) {
     if (c->difficulty < 1 || c->extend_dis < 0 || c->extend_dis > 8 || c->evader_view < 0) return PE_ERR_BAD_CONFIG;
     if (c->tape_len < 1 || c->max_path < c->difficulty + 2) return PE_ERR_BAD_CONFIG;
     if (lds_layout(*c, true, true, nullptr, nullptr) > 160 * 1024) return PE_ERR_BAD_CONFIG;
+    if (align16(sizeof(int16_t) * c->W * c->H) + sizeof(uint32_t) * WAVE * (raser_row_words(c->O) + 1) > 160 * 1024) return PE_ERR_BAD_CONFIG;
     return 0;
 }
 
@@ -1260,7 +1315,7 @@ int pe_env_reset(const pe_config *cfg, const pe_state *st, const pe_reset_params
     DevRng *rng = (DevRng *)reset_state;
     uint8_t *bank = (uint8_t *)reset_state + N * sizeof(DevRng);
     hipLaunchKernelGGL(k_reset, dim3(N), dim3(WAVE), lds, s, *cfg, *st, *prm, rng, bank, (int)first, d_obs, d_def, o_state);
-    hipLaunchKernelGGL(k_build_bidx, dim3(N), dim3(256), 0, s, *cfg, *st, (const int32_t *)d_obs, (const DevRng *)rng);
+    { const int rc2 = launch_episode_tables(cfg, st, d_obs, rng, s); if (rc2) return rc2; }
     int tot = (int)(N * P * 4);
     hipLaunchKernelGGL(k_def_aos_to_soa, dim3((tot + 255) / 256), dim3(256), 0, s, (int)N, (int)P, (const double *)d_def, st->def);
     if (reset_rn) PE_TRY(hipMemsetAsync(st->rn, 0, N * (1 + 2 * P) * sizeof(double), s));
@@ -1290,7 +1345,7 @@ int pe_env_load(const pe_config *cfg, const pe_state *st, const pe_host_init *h,
     PE_TRY(hipMallocAsync((void **)&d_def, N * P * 4 * sizeof(double), s));
     PE_TRY(hipMemcpyAsync(d_obs, h->obs_xy, N * cfg->O * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     PE_TRY(hipMemcpyAsync(d_def, h->def, N * P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_build_bidx, dim3(N), dim3(256), 0, s, *cfg, *st, (const int32_t *)d_obs, (const DevRng *)nullptr);
+    { const int rc2 = launch_episode_tables(cfg, st, d_obs, nullptr, s); if (rc2) return rc2; }
     int tot = (int)(N * P * 4);
     hipLaunchKernelGGL(k_def_aos_to_soa, dim3((tot + 255) / 256), dim3(256), 0, s, (int)N, (int)P, d_def, st->def);
     if (h->reset_rn) PE_TRY(hipMemsetAsync(st->rn, 0, N * (1 + 2 * P) * sizeof(double), s));

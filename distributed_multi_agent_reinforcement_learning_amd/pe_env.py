@@ -29,7 +29,7 @@ class PeConfig(C.Structure):
 
 class PeState(C.Structure):
     _fields_ = [("N", C.c_int32), ("pad0", C.c_int32)] + \
-               [(n, C.c_void_p) for n in ("grid", "bidx", "n_obs", "def_", "eva", "target", "tape", "meta", "path", "rn", "wpw", "lcache")]
+               [(n, C.c_void_p) for n in ("grid", "bidx", "n_obs", "def_", "eva", "target", "tape", "meta", "path", "rn", "wpw", "raser")]
 
 
 class PeObsOut(C.Structure):
@@ -122,6 +122,11 @@ def status_text(bits):
     return "; ".join(n for b, n in STATUS_NAMES if int(bits) & b)
 
 
+def raser_row_words(O):
+    """include/pe_env.h PE_RASER_ROW_WORDS"""
+    return (((O + 31) >> 5) + 3) & ~3
+
+
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed: {load_library().pe_error_string(rc).decode()} (code {rc})")
@@ -188,7 +193,7 @@ class BatchedEnv:
                        defs=z((N, 4, P), torch.float64), eva=z((N, 4), torch.float64), target=z((N, 2), torch.int32),
                        tape=z((N, c.tape_len, 2), torch.int32), meta=z((N, META_INTS), torch.int32),
                        path=z((N, c.max_path, 2), torch.int16), rn=z((N, 1 + 2 * P), torch.float64), wpw=z((N, 16), torch.int32),
-                       lcache=torch.full((N, P, 1 + (c.O + 31) // 32), -1, dtype=torch.int32, device=dev))
+                       raser=z((N, WH, raser_row_words(c.O)), torch.int32))
         self.o_state = z((N, c.O, 4), torch.float32)  # boundary obstacles as [x, y, 0, 0] (pursuit_env.py:22-26), padded
         self.st = PeState()
         self.st.N = N

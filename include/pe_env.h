@@ -23,6 +23,7 @@ extern "C" {
 #define PE_MAX_BEAMS 64
 #define PE_MAX_P 16          /* defenders per environment */
 #define PE_META_INTS 8
+#define PE_RASER_ROW_WORDS(O) (((((O) + 31) >> 5) + 3) & ~3)   /* 32-bit words per raser row (16-byte aligned rows) */
 #define PE_ERR_BAD_CONFIG 10001
 #define PE_ERR_NULL 10002
 #define PE_ERR_RESET_FAILED 10003 /* a placement loop of Pursuit_Env.reset hit PE_RESET_MAX_DRAWS (see below) */
@@ -79,8 +80,9 @@ typedef struct pe_state {
     double *rn;         /* [N][1+2P]     reward normaliser: n, mean[P], S[P] (DHGN/normalization.py:4-22)        */
     uint32_t *wpw;      /* [N][16]       the evader's next waypoints (x<<16|y) as of the last replan: path[cnt-1], path[cnt-2], ...;
                            lets the tick prefetch them with everything else instead of a read that depends on meta        */
-    uint32_t *lcache;   /* [N][P][1+ceil(O/32)] per-defender LiDAR cache: cell (x<<16|y, ~0 = empty) + O hit bits: the LiDAR row
-                           only depends on the defender's cell (pursuit_env.py:201), which changes every ~5 ticks          */
+    uint32_t *raser;    /* [N][W*H][RW]  the episode's raser map (pursuit_env.py:29-53 get_raser_map), bit-packed: bit k of row
+                           x*H+y = boundary obstacle k is the first hit of a LiDAR beam from cell (x, y); RW = PE_RASER_ROW_WORDS(O).
+                           Written by pe_env_reset / pe_env_load, read by the tick: o_adj[i] = raser[int(x_i)][int(y_i)]        */
 } pe_state;
 
 /* Observations, fp32, reference layouts (DHGN/mappo_parallel.py:767-771, replay_buffer.py:28-33).  Every tensor
@@ -164,8 +166,8 @@ int64_t pe_tick_lds_bytes(const pe_config *cfg, int32_t with_replan);
 /* Pursuit_Env.reset() hand-over: host initial conditions -> device records (pursuit_env.py:60-73). */
 int pe_env_load(const pe_config *cfg, const pe_state *st, const pe_host_init *init, void *stream);
 
-/* get_state + communicate + sensor (base_env.py:198-209, pursuit_env.py:182-209, agent.py:157-169, 319-341),
- * LiDAR evaluated on the fly instead of through the per-reset raser map (pursuit_env.py:29-53). */
+/* get_state + communicate + sensor (base_env.py:198-209, pursuit_env.py:182-209, agent.py:157-169, 319-341); the LiDAR
+ * rows come from the episode's raser table (pursuit_env.py:29-53, built on the device by pe_env_reset / pe_env_load). */
 int pe_env_observe(const pe_config *cfg, const pe_state *st, const pe_obs_out *out, void *stream);
 
 /* Pursuit_Env.attacker_step (pursuit_env.py:75-102) incl. Evader.replan / rescan / A* (agent.py:202-271,

@@ -54,6 +54,20 @@ def capture_trace(seed, P, W, H, blocks, variance, T, policy, save_raser):
         rec["e_adj"].append(np.asarray(e_adj, np.uint8))
         if policy == "demon":
             a = env.demon() if (t // 25) % 2 == 0 else list(rng.integers(0, 9, P))
+        elif policy == "stress":
+            # round 2: the order-dependent corner of Pursuit_Env.step -- run for the nearest map border (proposals leave the clip
+            # box, accepted ones are clipped in place), then herd towards the centroid (inner collisions), alternating
+            st = np.asarray(env.get_state('defender'), np.float64)
+            ang = np.arange(8) * np.pi / 4
+            if (t // 30) % 2 == 0:
+                db = np.stack((st[:, 0], W - 1 - st[:, 0], st[:, 1], H - 1 - st[:, 1]), -1)
+                want = np.array([np.pi, 0.0, -np.pi / 2, np.pi / 2])[db.argmin(-1)]
+            else:
+                cen = st[:, :2].mean(0)
+                want = np.arctan2(cen[1] - st[:, 1], cen[0] - st[:, 0])
+            a = [int(np.abs(np.angle(np.exp(1j * (w - ang)))).argmin()) for w in want]
+            if t % 7 == 3:
+                a[int(rng.integers(0, P))] = int(rng.integers(0, 9))
         else:
             a = list(rng.integers(0, 9, P))
         env.attacker_step()
@@ -153,11 +167,20 @@ def main():
         ("env_trace_40x40_p8_s3", 3, 8, 40, 40, 5, 10, 150, "random", False),
         ("env_trace_40x40_p8_s4", 4, 8, 40, 40, 5, 10, 150, "demon", False),
     ]
+    if "--stress-only" in sys.argv:   # round 2 additions (the round-1 fixtures above are unchanged)
+        jobs = []
+    jobs += [
+        ("env_trace_20x20_p4x_s5", 5, 4, 20, 20, 2, 4, 120, "stress", False),
+        ("env_trace_20x20_p4x_s6", 6, 4, 20, 20, 2, 4, 120, "stress", False),
+        ("env_trace_40x40_p8_s5", 5, 8, 40, 40, 5, 10, 150, "stress", False),
+    ]
     for (name, seed, P, W, H, blocks, var, T, pol, ras) in jobs:
         out = capture_trace(seed, P, W, H, blocks, var, T, pol, ras)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
         print(name, "n_obs", int(out["n_obs"]), "redraws", len(out["drawn_targets"]) - 1, "sum r", out["reward"].sum(),
               "e_adj hits", int(out["e_adj"].sum()), flush=True)
+    if "--stress-only" in sys.argv:
+        return
     np.savez_compressed(os.path.join(OUT, "astar_cases.npz"), **capture_astar_cases())
     np.savez_compressed(os.path.join(OUT, "reward_norm.npz"), **capture_reward_norm())
     print("done")

@@ -41,7 +41,7 @@ def test_device_f64_primitives_match_host():
             assert same.all(), f"{name}: {np.sum(~same)} of {n} differ"
 
 
-@pytest.mark.parametrize("group", ["20x20_p4", "40x40_p8"])
+@pytest.mark.parametrize("group", ["20x20_p4", "20x20_p4x", "40x40_p8"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_trace_parity(group, fused):
     traces = [load_trace(p) for p in trace_files(f"env_trace_{group}_*.npz")]
@@ -306,7 +306,7 @@ def test_edge_configurations_match_oracle(P, W, H, blocks, variance):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("group", ["20x20_p4", "40x40_p8"])
+@pytest.mark.parametrize("group", ["20x20_p4", "20x20_p4x", "40x40_p8"])
 def test_device_reset_reproduces_reference_goldens(group):
     """k_reset (Pursuit_Env.reset on the device, the default reset path) against the REFERENCE's own initial conditions:
     a DeviceResetter seeded with the golden traces' seeds must produce their grid, boundary obstacles in index order,
@@ -361,9 +361,68 @@ def test_lidar_full_map_sweep_matches_reference_raser_maps():
         init["defenders"][:, :, :2] = xy.reshape(N, P, 2)
         env.load(init, reset_reward_norm=True)
         obs = env.new_obs()
-        for rep in range(2):                                                        # second launch: served from the LiDAR cache
+        for rep in range(2):
             env.observe(obs)
             oa = obs["o_adj"].cpu().numpy().reshape(N * P, -1)
             want = d["raser"].reshape(W * H, k)[cells].astype(np.float32)
             assert np.array_equal(oa[:, :k], want), (d["seed"], rep, int((oa[:, :k] != want).sum()))
             assert not oa[:, k:].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [3, 4, 7, 8])
+def test_step_scoring_stress_matches_oracle(P):
+    """Pursuit_Env.step's order-dependent scoring (pursuit_env.py:104-177) under the conditions that exercise it:
+    small maps, defenders pushed against the map border (proposals outside the clip box get clipped in place once accepted and
+    then count for the defenders behind them), herded together (inner collisions) and along obstacle edges (all nine probes).
+    The kernel resolves the sequential rule on wave masks for P <= 8 (csrc/pe_env.hip dev_step FAST8): rewards, accepted moves
+    and f64 positions must equal the sequential oracle at every step."""
+    W, H, T, N = 14, 17, 80, 192
+    cfg = product_cfg(P, W, H, T, blocks=2, variance=3, **{"map.center": [W // 2, H // 2]})
+    env = _env(cfg, N)
+    rng = np.random.default_rng(P)
+    base = random_init(N, 2, W, H, 2, 3, seed=9000 + P)       # maps, evader, target from the reset restatement ...
+    init = dict(base, defenders=np.zeros((N, P, 4)))
+    for n in range(N):                                          # ... defenders anywhere on free cells, > 1.2 apart (the reference's
+        pts = []                                                # placement rule admits at most ~4 defenders on a map this small)
+        while len(pts) < P:
+            q = rng.uniform(0, [W - 1, H - 1])
+            if base["grid"][n, int(round(q[0])), int(round(q[1]))] == 0 and all(np.hypot(*(q - r)) > 1.2 for r in pts):
+                pts.append(q)
+        init["defenders"][n, :, :2] = np.asarray(pts)
+    env.load(init, reset_reward_norm=True)
+    ocfg, oenvs = oracle_envs_from_init(init, P, W, H, T)
+    obs = env.new_obs()
+    reward = torch.zeros((N, P), dtype=torch.float32, device="cuda")
+    raw = torch.zeros((N, P), dtype=torch.float32, device="cuda")
+    env.observe(obs); env.evader_step()
+    ang = np.arange(8) * np.pi / 4
+    n_rej = n_clip = 0
+    for t in range(T):
+        defs = env.defenders_aos().cpu().numpy()
+        # a third of the environments herd towards the centroid, a third run for the nearest border, the rest act randomly
+        acts = rng.integers(0, 9, (N, P)).astype(np.int32)
+        cen = defs[:, :, :2].mean(1, keepdims=True)
+        to_c = np.arctan2(cen[..., 1] - defs[..., 1], cen[..., 0] - defs[..., 0])
+        dist_b = np.stack((defs[..., 0], W - 1 - defs[..., 0], defs[..., 1], H - 1 - defs[..., 1]), -1)
+        to_b = np.array([np.pi, 0.0, -np.pi / 2, np.pi / 2])[dist_b.argmin(-1)]
+        pick = lambda a: np.abs(np.angle(np.exp(1j * (a[..., None] - ang)))).argmin(-1).astype(np.int32)
+        mode = (np.arange(N) % 3)[:, None]
+        acts = np.where(mode == 0, pick(to_c), np.where(mode == 1, pick(to_b), acts)).astype(np.int32)
+        o_dev = {k: v.cpu().numpy() for k, v in obs.items()}
+        for n, oe in enumerate(oenvs):
+            ps, es, pa, ea, oa = oe.observe()
+            oe.evader_step()
+            assert np.array_equal(o_dev["p_state"][n], ps) and np.array_equal(o_dev["p_adj"][n], pa) and np.array_equal(o_dev["o_adj"][n], oa), (t, n)
+            assert np.array_equal(o_dev["e_adj"][n], ea), (t, n)
+        env.tick(torch.as_tensor(acts).cuda(), obs, reward, raw)
+        r_raw = raw.cpu().numpy(); after = env.defenders_aos().cpu().numpy()
+        for n, oe in enumerate(oenvs):
+            r, ok, _ = oe.step(acts[n])
+            oe.reward_norm(r)
+            assert np.array_equal(r_raw[n], r.astype(np.float32)), (t, n, r_raw[n], r)
+            assert np.array_equal(after[n], oe.state()["defenders"]), (t, n)
+            n_rej += int((np.asarray(ok) == 0).sum())
+        n_clip += int(((after[..., 0] == 0) | (after[..., 0] == W - 1) | (after[..., 1] == 0) | (after[..., 1] == H - 1)).sum())
+    assert n_rej > 50 and n_clip > 50, (n_rej, n_clip)   # the stress actually happened
+    assert not env.status().any().item()

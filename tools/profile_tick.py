@@ -30,11 +30,35 @@ for ep in range(args.episodes):
     acts = torch.randint(0, 9, (T, N, P), dtype=torch.int32, device="cuda", generator=g)
     env.observe(obs)
     env.attacker_step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(T)]
+    ev[0].record()
+    kinds = []
     for t in range(T - 1):
         env.tick(acts[t], obs, reward)
-    e1.record()
+        kinds.append(env.sim.t_host % env.pe_cfg.difficulty == 0)
+        ev[t + 1].record()
     torch.cuda.synchronize()
-    print(f"episode {ep}: {e0.elapsed_time(e1) / (T - 1) * 1e3:.2f} us per tick launch (avg incl. replan ticks), "
+    dur = [ev[t].elapsed_time(ev[t + 1]) * 1e3 for t in range(T - 1)]
+    reg = sorted(d for d, k in zip(dur, kinds) if not k)
+    rep = [d for d, k in zip(dur, kinds) if k]
+    print(f"episode {ep}: regular tick {sum(reg) / len(reg):.2f} us avg, {reg[len(reg) // 2]:.2f} median, {reg[0]:.2f} min; replan tick "
+          f"{sum(rep) / max(1, len(rep)):.1f} us avg, {max(rep) if rep else 0:.1f} max; all ticks {sum(dur) / len(dur):.2f} us avg; "
           f"status bits {int(env.sim.status().max())}, mean A* expansions {float(env.sim.meta[:, 5].float().mean()):.1f}")
+
+# per-phase launches (each pays its own prologue): step only, observe only, evader only (no replan)
+def timeit(fn, n=40):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+env.reset()
+env.observe(obs); env.attacker_step()
+a0 = acts[0]
+env.sim.t_host = 1  # not a replan tick
+t_step = timeit(lambda: (env.sim.step(a0, reward), setattr(env.sim, "t_host", 1)))
+t_obs = timeit(lambda: env.sim.observe(obs))
+t_eva = timeit(lambda: env.sim.evader_step())
+print(f"phase launches: step {t_step:.2f} us, observe {t_obs:.2f} us, evader(no replan) {t_eva:.2f} us")
