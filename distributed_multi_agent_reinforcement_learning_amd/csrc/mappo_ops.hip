@@ -16,7 +16,7 @@ constexpr int MAX_P = 16;
 
 struct MsgArgs {
     int R, P, K, E, din, q_div, adj_mode;
-    const float *p, *q, *e, *adj;
+    const float *p, *q, *e, *adj;  // adj: float [R][P][K], or uint32 words (MO_ADJ_BITS)
     int64_t p_rs, q_rs, e_rs, adj_rs;  // row strides in elements (rows may be slices of (N, T, ...) buffers)
     int64_t o_is;                       // elements between consecutive (row, agent) vectors of out / gout
     const int32_t *kvalid;
@@ -34,6 +34,7 @@ __device__ __forceinline__ void stage_row(const MsgArgs &a, int r, float *s_p, f
         float4 *dst = (float4 *)s_q;
         for (int i = tid; i < K; i += nthr) dst[i] = src[i];
     }
+    const int RWK = MO_ADJ_ROW_WORDS(K);
     if (a.adj_mode == MO_ADJ_TENSOR) {
         const float *src = a.adj + (size_t)r * a.adj_rs;
         if (((P * K) & 3) == 0 && (a.adj_rs & 3) == 0) {
@@ -41,6 +42,9 @@ __device__ __forceinline__ void stage_row(const MsgArgs &a, int r, float *s_p, f
         } else {
             for (int i = tid; i < P * K; i += nthr) s_adj[i] = src[i];
         }
+    } else if (a.adj_mode == MO_ADJ_BITS) {  // P rows of RWK words: 1/29 of the bytes of the float adjacency
+        const uint32_t *src = (const uint32_t *)a.adj + (size_t)r * a.adj_rs;
+        for (int i = tid; i < P * RWK; i += nthr) ((uint32_t *)s_adj)[i] = src[i];
     }
     __syncthreads();
     if (a.adj_mode == MO_ADJ_TENSOR) {
@@ -49,11 +53,23 @@ __device__ __forceinline__ void stage_row(const MsgArgs &a, int r, float *s_p, f
             for (int i = 0; i < P; i++) m |= (s_adj[i * K + j] != 0.f) ? (1u << i) : 0u;
             s_col[j] = m;
         }
+    } else if (a.adj_mode == MO_ADJ_BITS) {
+        const uint32_t *sw = (const uint32_t *)s_adj;
+        for (int j = tid; j < K; j += nthr) {
+            unsigned int m = 0;
+            for (int i = 0; i < P; i++) m |= ((sw[i * RWK + (j >> 5)] >> (j & 31)) & 1u) << i;
+            s_col[j] = m;
+        }
     }
     if (tid < P) {
         float s = 0.f;
         if (a.adj_mode == MO_ADJ_TENSOR) {
             for (int j = 0; j < K; j++) s += fabsf(s_adj[tid * K + j]);
+        } else if (a.adj_mode == MO_ADJ_BITS) {  // sum of K ones and zeros: exact in fp32, any order
+            const uint32_t *sw = (const uint32_t *)s_adj;
+            int cnt = 0;
+            for (int w = 0; w < (K + 31) >> 5; w++) cnt += __popc(sw[tid * RWK + w] & ((w == (K >> 5)) ? ((1u << (K & 31)) - 1u) : 0xFFFFFFFFu));
+            s = (float)cnt;
         } else if (a.adj_mode == MO_ADJ_ONES) {
             s = (float)K;
         } else {
@@ -67,12 +83,20 @@ __device__ __forceinline__ void stage_row(const MsgArgs &a, int r, float *s_p, f
     __syncthreads();
 }
 
+__host__ __device__ inline int msg_adj_floats(int P, int K) {  // the adjacency stage holds float [P][K] or packed rows
+    const int f = (P * K + 3) & ~3, w = P * MO_ADJ_ROW_WORDS(K);
+    return f > w ? f : w;
+}
+// d_j = W[:, :4] q_j with a fixed evaluation order (explicit fused multiply-adds: every loop variant rounds identically)
+__device__ __forceinline__ float msg_dot4(const float *w, const float4 &qv) {
+    return __builtin_fmaf(w[3], qv.w, __builtin_fmaf(w[2], qv.z, __builtin_fmaf(w[1], qv.y, w[0] * qv.x)));
+}
 struct MsgLds { float *q, *adj, *p, *pe, *inv; unsigned int *col; };
 __device__ __forceinline__ MsgLds msg_lds(float *smem, int P, int K) {
     MsgLds l;
     l.q = smem;
     l.adj = l.q + K * 4;
-    l.p = l.adj + ((P * K + 3) & ~3);
+    l.p = l.adj + msg_adj_floats(P, K);
     l.pe = l.p + P * 4;
     l.inv = l.pe + P * 4;
     l.col = (unsigned int *)(l.inv + MAX_P);
@@ -107,20 +131,22 @@ __global__ void k_msg_agg_fwd(MsgArgs a, float *out) {
                 if (a.din == 8) c[i] += w[4] * l.pe[i * 4] + w[5] * l.pe[i * 4 + 1] + w[6] * l.pe[i * 4 + 2] + w[7] * l.pe[i * 4 + 3];
             }
         }
-        if (a.adj_mode == MO_ADJ_TENSOR) {
+        if (a.adj_mode == MO_ADJ_TENSOR || a.adj_mode == MO_ADJ_BITS) {
+            // one instruction stream for both adjacency forms (a packed entry is the weight 1.f), so they agree bit for bit
+            const bool bits = a.adj_mode == MO_ADJ_BITS;
             for (int j = 0; j < K; j++) {
                 const unsigned int m = l.col[j];
                 if (m == 0u) continue;  // wave-uniform
                 const float4 qv = ((const float4 *)l.q)[j];
-                const float d = w[0] * qv.x + w[1] * qv.y + w[2] * qv.z + w[3] * qv.w;
+                const float d = msg_dot4(w, qv);
 #pragma unroll
                 for (int i = 0; i < PT; i++)
-                    if (m & (1u << i)) acc[i] += l.adj[i * K + j] * fmaxf(c[i] - d, 0.f);
+                    if (m & (1u << i)) acc[i] = __builtin_fmaf(bits ? 1.f : l.adj[i * K + j], fmaxf(c[i] - d, 0.f), acc[i]);
             }
         } else {
             for (int j = 0; j < kv; j++) {
                 const float4 qv = ((const float4 *)l.q)[j];
-                const float d = w[0] * qv.x + w[1] * qv.y + w[2] * qv.z + w[3] * qv.w;
+                const float d = msg_dot4(w, qv);
 #pragma unroll
                 for (int i = 0; i < PT; i++) acc[i] += fmaxf(c[i] - d, 0.f);
             }
@@ -160,26 +186,27 @@ __global__ void k_msg_agg_bwd(MsgArgs a, const float *gout, float *partials) {
             }
         }
         float hq0 = 0.f, hq1 = 0.f, hq2 = 0.f, hq3 = 0.f;
-        if (a.adj_mode == MO_ADJ_TENSOR) {
+        if (a.adj_mode == MO_ADJ_TENSOR || a.adj_mode == MO_ADJ_BITS) {
+            const bool bits = a.adj_mode == MO_ADJ_BITS;  // 0/1 adjacency: the set entries are exactly 1
             for (int j = 0; j < K; j++) {
                 const unsigned int m = l.col[j];
                 if (m == 0u) continue;
                 const float4 qv = ((const float4 *)l.q)[j];
-                const float d = w[0] * qv.x + w[1] * qv.y + w[2] * qv.z + w[3] * qv.w;
+                const float d = msg_dot4(w, qv);
                 float hj = 0.f;
 #pragma unroll
                 for (int i = 0; i < PT; i++)
                     if (m & (1u << i)) {
-                        const float g = (c[i] - d > 0.f) ? gi[i] * l.adj[i * K + j] : 0.f;
+                        const float g = (c[i] - d > 0.f) ? gi[i] * (bits ? 1.f : l.adj[i * K + j]) : 0.f;
                         G[i] += g;
                         hj += g;
                     }
-                hq0 += hj * qv.x; hq1 += hj * qv.y; hq2 += hj * qv.z; hq3 += hj * qv.w;
+                hq0 = __builtin_fmaf(hj, qv.x, hq0); hq1 = __builtin_fmaf(hj, qv.y, hq1); hq2 = __builtin_fmaf(hj, qv.z, hq2); hq3 = __builtin_fmaf(hj, qv.w, hq3);
             }
         } else {
             for (int j = 0; j < kv; j++) {
                 const float4 qv = ((const float4 *)l.q)[j];
-                const float d = w[0] * qv.x + w[1] * qv.y + w[2] * qv.z + w[3] * qv.w;
+                const float d = msg_dot4(w, qv);
                 float hj = 0.f;
 #pragma unroll
                 for (int i = 0; i < PT; i++) {
@@ -187,7 +214,7 @@ __global__ void k_msg_agg_bwd(MsgArgs a, const float *gout, float *partials) {
                     G[i] += g;
                     hj += g;
                 }
-                hq0 += hj * qv.x; hq1 += hj * qv.y; hq2 += hj * qv.z; hq3 += hj * qv.w;
+                hq0 = __builtin_fmaf(hj, qv.x, hq0); hq1 = __builtin_fmaf(hj, qv.y, hq1); hq2 = __builtin_fmaf(hj, qv.z, hq2); hq3 = __builtin_fmaf(hj, qv.w, hq3);
             }
         }
 #pragma unroll
@@ -683,13 +710,13 @@ __global__ void k_gru_bias_reduce(int nblk, const float *partials, float *db_ih,
     }
 }
 
-size_t msg_lds_bytes(int P, int K) { return sizeof(float) * (size_t)(K * 4 + ((P * K + 3) & ~3) + P * 4 + P * 4 + MAX_P + K + 4); }
+size_t msg_lds_bytes(int P, int K) { return sizeof(float) * (size_t)(K * 4 + msg_adj_floats(P, K) + P * 4 + P * 4 + MAX_P + K + 4); }
 
 int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, const void *adj, const void *kvalid, const void *e) {
     if (R < 0 || P < 1 || P > MAX_P || K < 1 || E < 64 || E > 256 || (E & 63) || (din != 4 && din != 8) || q_div < 1) return MO_ERR_BAD_ARG;
-    if (adj_mode == MO_ADJ_TENSOR && !adj) return MO_ERR_BAD_ARG;
+    if ((adj_mode == MO_ADJ_TENSOR || adj_mode == MO_ADJ_BITS) && !adj) return MO_ERR_BAD_ARG;
     if (adj_mode == MO_ADJ_VALID && !kvalid) return MO_ERR_BAD_ARG;
-    if (adj_mode < 0 || adj_mode > 2) return MO_ERR_BAD_ARG;
+    if (adj_mode < 0 || adj_mode > 3) return MO_ERR_BAD_ARG;
     if (din == 8 && !e) return MO_ERR_BAD_ARG;
     if (msg_lds_bytes(P, K) > 64 * 1024) return MO_ERR_BAD_ARG;
     return 0;
@@ -943,13 +970,13 @@ int wgrad_split(int M, int N, int *am, int *bn) {  // tile shape and number of K
 extern "C" {
 
 int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
-                     int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const float *adj, int64_t adj_rs, int32_t adj_mode,
+                     int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const void *adj, int64_t adj_rs, int32_t adj_mode,
                      const int32_t *kvalid, const float *W, const float *b, float *out, int64_t out_stride, void *stream) {
     int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
     if (rc) return rc;
     if (R == 0) return 0;
     if ((q_rs & 3) || out_stride < E) return MO_ERR_BAD_ARG;
-    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, p_rs, q_rs, e_rs, adj_rs, out_stride, kvalid, W, b};
+    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, (const float *)adj, p_rs, q_rs, e_rs, adj_rs, out_stride, kvalid, W, b};
     const int grid = R < 8192 ? R : 8192;
     if (P <= 4) hipLaunchKernelGGL(k_msg_agg_fwd<4>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
     else if (P <= 8) hipLaunchKernelGGL(k_msg_agg_fwd<8>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
@@ -960,14 +987,14 @@ int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD_BLOCKS * (din + 1) * E * sizeof(float); }
 
 int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
-                     int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const float *adj, int64_t adj_rs, int32_t adj_mode,
+                     int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const void *adj, int64_t adj_rs, int32_t adj_mode,
                      const int32_t *kvalid, const float *W, const float *b, const float *gout, int64_t gout_stride, float *dW, float *db,
                      void *workspace, void *stream) {
     int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
     if (rc) return rc;
     if (!workspace || !gout || !dW || !db) return MO_ERR_BAD_ARG;
     if ((q_rs & 3) || gout_stride < E) return MO_ERR_BAD_ARG;
-    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, adj, p_rs, q_rs, e_rs, adj_rs, gout_stride, kvalid, W, b};
+    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, (const float *)adj, p_rs, q_rs, e_rs, adj_rs, gout_stride, kvalid, W, b};
     const int grid = R < BWD_BLOCKS ? (R > 0 ? R : 1) : BWD_BLOCKS;
     if (P <= 4) hipLaunchKernelGGL(k_msg_agg_bwd<4>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);
     else if (P <= 8) hipLaunchKernelGGL(k_msg_agg_bwd<8>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);

@@ -375,7 +375,8 @@ __device__ void dev_observe(const pe_config &c, const SqThr &th, const Lds &l, i
     const int P = c.P, O = c.O, RW = raser_row_words(O);
     uint32_t r_row = 0u;
     const bool one_load = P * RW <= WAVE;
-    if (o.o_adj && one_load && lane < P * RW) {
+    const bool want_rows = o.o_adj || o.o_adj_bits;
+    if (want_rows && one_load && lane < P * RW) {
         const int i = th.rw_shift >= 0 ? lane >> th.rw_shift : lane / RW, w = lane - i * RW;
         const int cell = (int)l.def[i] * c.H + (int)l.def[P + i];
         r_row = raser_env[(size_t)cell * RW + w];  // in flight during the adjacency / line-of-sight work below
@@ -420,15 +421,23 @@ __device__ void dev_observe(const pe_config &c, const SqThr &th, const Lds &l, i
         }
         o.e_adj[(int64_t)env * o.e_adj_stride + lane] = seen;
     }
-    if (o.o_adj) {
+    if (want_rows) {
+        uint32_t *bits = o.o_adj_bits ? o.o_adj_bits + (int64_t)env * o.o_adj_bits_stride : nullptr;
         if (one_load) {
-            if (lane < P * RW) l.rw[lane] = r_row;
+            if (lane < P * RW) {
+                if (o.o_adj) l.rw[lane] = r_row;
+                if (bits) bits[lane] = r_row;
+            }
         } else {
             for (int idx = lane; idx < P * RW; idx += WAVE) {
                 const int i = idx / RW, w = idx - i * RW;
-                l.rw[idx] = raser_env[(size_t)((int)l.def[i] * c.H + (int)l.def[P + i]) * RW + w];
+                const uint32_t v = raser_env[(size_t)((int)l.def[i] * c.H + (int)l.def[P + i]) * RW + w];
+                l.rw[idx] = v;
+                if (bits) bits[idx] = v;
             }
         }
+    }
+    if (o.o_adj) {
         wave_sync();
         // hit bits -> fp32 rows, four obstacles (16 bytes) per lane and store: the P rows of O floats are contiguous
         float *dst = o.o_adj + (int64_t)env * o.o_adj_stride;

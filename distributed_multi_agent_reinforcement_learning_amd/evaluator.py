@@ -31,7 +31,7 @@ def evaluate(env, actor, cfg, init=None, return_actions=False):
     episode_reward = torch.zeros(N, device=device)
     reward = torch.zeros(N, P, device=device)
     raw = torch.zeros(N, P, device=device)
-    obs = env.sim.new_obs()
+    obs = env.sim.new_obs(packed=True)  # LiDAR rows bit-packed, as in the rollout
     actions = []
     env.observe(obs)
     env.attacker_step()

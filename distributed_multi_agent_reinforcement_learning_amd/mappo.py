@@ -19,6 +19,22 @@ BUFFER_KEYS = ("p_state", "e_state", "o_state", "p_adj", "e_adj", "o_adj", "acto
                "critic_historical_embedding", "v_n", "a_n", "a_logprob_n", "r", "active")
 
 
+class _Buffer(dict):
+    """The reference's buffer dict.  `o_adj` (N, T, P, O) fp32 -- 3.5 GB at 4096 environments, 1/29 of it information -- is
+    STORED bit-packed as `o_adj_bits` (N, T, P, RW) int32, the form the env kernel emits and the msg-agg kernels read; the
+    reference-layout key is materialised on first access (tests, tools, a user's own code), never on the hot path."""
+
+    def __missing__(self, key):
+        if key == "o_adj" and "o_adj_bits" in self:
+            v = ops.unpack_adj_bits(self["o_adj_bits"], self.num_obstacle_slots)
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+    def stored_items(self):
+        return [(k, v) for k, v in self.items() if k not in ("o_adj", "o_state")]
+
+
 class ReplayBuffer:
     """Zero-padded episode buffer with the reference's keys and (N, T, ...) layouts (DHGN/replay_buffer.py:24-40),
     resident in HBM.  `o_state` is stored once per episode as (N, O, 4) (`o_static`) and exposed in the reference's
@@ -37,12 +53,13 @@ class ReplayBuffer:
     def reset_buffer(self):
         N, T, P, O, E, d = self.batch_size, self.episode_limit, self.max_p_num, self.max_o_num, self.embedding_size, self.depth
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
-        b = dict()
+        b = _Buffer()
+        b.num_obstacle_slots = O
         b["p_state"] = z(N, T, P, self.p_dim)
         b["e_state"] = z(N, T, self.max_e_num, self.e_dim)
         b["p_adj"] = z(N, T, P, P)
         b["e_adj"] = z(N, T, P, self.max_e_num)
-        b["o_adj"] = z(N, T, P, O)
+        b["o_adj_bits"] = torch.zeros((N, T, P, ops.adj_row_words(O)), dtype=torch.int32, device=self.device)
         b["actor_historical_embedding"] = z(N, T + d, P, E)
         b["critic_historical_embedding"] = z(N, T + d, P, E)
         b["v_n"] = z(N, T + 1, P)
@@ -64,6 +81,8 @@ class ReplayBuffer:
         for k in BUFFER_KEYS:
             if k == "o_state":
                 rb.o_static.copy_(tensors[k][:, 0])
+            elif k == "o_adj":
+                rb.buffer["o_adj_bits"].copy_(ops.pack_adj_bits(tensors[k].to(rb.device)))
             else:
                 rb.buffer[k].copy_(tensors[k])
         if o_kvalid is not None:
@@ -84,13 +103,15 @@ class BigBuffer:
 
     def concat_buffer(self, mini_buffer):
         if self.buffer is None:
-            self.buffer = dict(mini_buffer.buffer)
+            self.buffer = _Buffer(mini_buffer.buffer.stored_items())
+            self.buffer.num_obstacle_slots = mini_buffer.buffer.num_obstacle_slots
+            self.buffer["o_state"] = mini_buffer.buffer["o_state"]
             self.o_static = mini_buffer.o_static
         else:
             self.o_static = torch.cat([self.o_static, mini_buffer.o_static], dim=0)
-            for key in self.buffer:
-                if key != "o_state":
-                    self.buffer[key] = torch.cat([self.buffer[key], mini_buffer.buffer[key]], dim=0)
+            self.buffer.pop("o_adj", None)  # a materialised view of the old rows
+            for key, _ in self.buffer.stored_items():
+                self.buffer[key] = torch.cat([self.buffer[key], mini_buffer.buffer[key]], dim=0)
             N, T = self.buffer["r"].shape[:2]
             self.buffer["o_state"] = self.o_static[:, None].expand(N, T, *self.o_static.shape[1:])
 
@@ -98,9 +119,9 @@ class BigBuffer:
         device = torch.device(device)
         if self.o_static.device != device:
             self.o_static = self.o_static.to(device)
-            for key in self.buffer:
-                if key != "o_state":
-                    self.buffer[key] = self.buffer[key].to(device)
+            self.buffer.pop("o_adj", None)
+            for key, _ in self.buffer.stored_items():
+                self.buffer[key] = self.buffer[key].to(device)
             N, T = self.buffer["r"].shape[:2]
             self.buffer["o_state"] = self.o_static[:, None].expand(N, T, *self.o_static.shape[1:])
         return self.buffer
@@ -164,7 +185,7 @@ class MAPPO:
             R = mb * T
             obs = dict(p_state=batch["p_state"][n0:n1].reshape(R, P, -1), e_state=batch["e_state"][n0:n1].reshape(R, 1, -1),
                        o_state=o_static[n0:n1], q_div=T, p_adj=batch["p_adj"][n0:n1].reshape(R, P, P),
-                       e_adj=batch["e_adj"][n0:n1].reshape(R, P, 1), o_adj=batch["o_adj"][n0:n1].reshape(R, P, -1))
+                       e_adj=batch["e_adj"][n0:n1].reshape(R, P, 1), o_adj_bits=batch["o_adj_bits"][n0:n1].reshape(R, P, -1))
             # EmbeddingDataset2 (:95-113): hop k reads the stored embeddings of step t-1-k (clean per-net history)
             hist_a = [batch["actor_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
             hist_c = [batch["critic_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
@@ -229,7 +250,7 @@ class MAPPO:
         self.minibuffer.o_kvalid[rows].copy_(st.o_kvalid)
         episode_reward = torch.zeros(N, device=self.device)
         raw = st.raw
-        obs_keys = ("p_state", "e_state", "p_adj", "e_adj", "o_adj")
+        obs_keys = ("p_state", "e_state", "p_adj", "e_adj", "o_adj_bits")
         env.observe(st.obs)
         env.attacker_step()
         use_graph = self.use_graphs and actions_override is None
@@ -282,7 +303,8 @@ class _RolloutState:
         dev = agent.device
         self.N, self.P, self.d = N, P, d
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        self.obs = dict(p_state=z(N, P, 4), e_state=z(N, 1, 4), p_adj=z(N, P, P), e_adj=z(N, P, 1), o_adj=z(N, P, O))
+        self.obs = dict(p_state=z(N, P, 4), e_state=z(N, 1, 4), p_adj=z(N, P, P), e_adj=z(N, P, 1),
+                        o_adj_bits=torch.zeros((N, P, ops.adj_row_words(O)), dtype=torch.int32, device=dev))  # LiDAR rows, bit-packed
         self.o_state = z(N, O, 4)
         self.o_kvalid = torch.zeros(N, dtype=torch.int32, device=dev)
         self.ha, self.hc = z(L, N * P, H), z(L, N * P, H)

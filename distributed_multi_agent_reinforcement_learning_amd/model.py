@@ -61,7 +61,7 @@ class DHGN(nn.Module):
 
     # -- encoder (:241-304) ----------------------------------------------------------------------------
     def encoder(self, p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid=None, q_div=1, out=None):
-        """p (R,P,4), e (R,1,4), o (R/q_div,O,4), adj_* (R,P,{P,1,O}) -> h0 (R,P,E).
+        """p (R,P,4), e (R,1,4), o (R/q_div,O,4), adj_* (R,P,{P,1,O}) (adj_o may be bit-packed int32 rows) -> h0 (R,P,E).
         is_critic: adjacency := ones (AttributeDataset, :64-65); in a batched rollout the obstacle relation uses ones
         over the first o_kvalid[row] (real) obstacles, in training over all padded slots."""
         R, P = p.shape[0], p.shape[1]
@@ -105,6 +105,12 @@ class DHGN(nn.Module):
         """out (R,P,E), rollout only: the embedding is written into it (static storage of the captured tick program)."""
         h0 = self.encoder(p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid, q_div, out if self.depth == 0 else None)
         return self.fcra(h0, hist, adj_p, is_critic, out)
+
+
+def _o_adj(obs):
+    """the obstacle adjacency of an observation dict: bit-packed rows (`o_adj_bits`, int32; what the env kernel emits and the
+    replay buffer stores) when present, else the reference-layout float rows `o_adj`"""
+    return obs["o_adj_bits"] if "o_adj_bits" in obs else obs["o_adj"]
 
 
 class _Trunk(nn.Module):
@@ -151,7 +157,7 @@ class SharedActor(_Trunk):
     def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, inplace_hidden=False, emb_out=None):
         """mode 0 (one step for R environments): returns prob (R,P,A), hidden, embedding (R,P,E)   (:422-425)
         mode 1 (sequences, rows ordered (episode, step)): returns prob (batch,steps,P,A), None, embedding  (:426-437)"""
-        emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], obs["o_adj"], hist,
+        emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist,
                               False, None, obs.get("q_div", 1), emb_out)
         if mode == 0:
             feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)
@@ -181,7 +187,7 @@ class SharedCritic(_Trunk):
     def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, rollout=False, inplace_hidden=False,
                 emb_out=None):
         kvalid = obs.get("o_kvalid") if rollout else None
-        emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], obs["o_adj"], hist,
+        emb = self.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist,
                               True, kvalid, obs.get("q_div", 1), emb_out)
         if mode == 0:
             feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from . import build as _build
 
-ADJ_TENSOR, ADJ_ONES, ADJ_VALID = 0, 1, 2
+ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
            "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
@@ -77,6 +77,32 @@ def _need_gpu(t, name):
         raise RuntimeError(f"{name}: tensor is on {t.device}; the fused HIP ops run on the GPU only (no CPU fallback)")
 
 
+def adj_row_words(K):
+    """include/mappo_ops.h MO_ADJ_ROW_WORDS: 32-bit words of one bit-packed adjacency row of K neighbours"""
+    return (((K + 31) >> 5) + 3) & ~3
+
+
+def pack_adj_bits(adj):
+    """(..., K) 0/1 float adjacency -> (..., adj_row_words(K)) int32, bit j of the row = adj[..., j] (the env's o_adj_bits
+    layout).  Plain torch: used for fixtures and tests, the rollout gets the packed rows straight from the env kernel."""
+    K = adj.shape[-1]
+    RW = adj_row_words(K)
+    b = (adj != 0).to(torch.int64)
+    pad = RW * 32 - K
+    if pad:
+        b = torch.cat((b, b.new_zeros(*b.shape[:-1], pad)), -1)
+    b = b.reshape(*b.shape[:-1], RW, 32)
+    w = (b << torch.arange(32, device=adj.device, dtype=torch.int64)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+
+def unpack_adj_bits(bits, K):
+    """inverse of pack_adj_bits: (..., RW) int32 -> (..., K) float32"""
+    sh = torch.arange(32, device=bits.device, dtype=torch.int32)
+    b = (bits.unsqueeze(-1) >> sh) & 1
+    return b.reshape(*bits.shape[:-1], -1)[..., :K].to(torch.float32)
+
+
 def _rows_ok(t):
     """each row (dim 0) is a dense block; rows may be strided (a slice buffer[:, t] of an (N, T, ...) tensor)"""
     return t[0].is_contiguous() and (t.shape[0] == 1 or t.stride(0) >= t[0].numel())
@@ -104,12 +130,14 @@ def _msg_call(kind, L, p, q, e, adj, kvalid, W, b, adj_mode, q_div, io, io_strid
     assert _rows_ok(q) and q.shape[2] == 4 and q.shape[0] * q_div == R and q.stride(0) % 4 == 0
     if adj_mode == ADJ_TENSOR:
         assert adj.shape == (R, P, K) and adj.dtype == torch.float32 and _rows_ok(adj)
+    if adj_mode == ADJ_BITS:
+        assert adj.shape == (R, P, adj_row_words(K)) and adj.dtype == torch.int32 and _rows_ok(adj)
     if e is not None:
         assert e.shape == (R, 4) and _rows_ok(e)
     if adj_mode == ADJ_VALID:
         assert kvalid.dtype == torch.int32 and kvalid.is_contiguous() and kvalid.shape[0] * q_div == R
     args = (R, P, K, E, din, _ptr(p), p.stride(0), _ptr(q), q.stride(0), q_div, _ptr(e), e.stride(0) if e is not None else 0,
-            _ptr(adj) if adj_mode == ADJ_TENSOR else None, adj.stride(0) if adj_mode == ADJ_TENSOR else 0, adj_mode,
+            _ptr(adj) if adj_mode in (ADJ_TENSOR, ADJ_BITS) else None, adj.stride(0) if adj_mode in (ADJ_TENSOR, ADJ_BITS) else 0, adj_mode,
             _ptr(kvalid) if adj_mode == ADJ_VALID else None, _ptr(W), _ptr(b), io, io_stride)
     if kind == "fwd":
         _check(L.dhgn_msg_agg_fwd(*args, _stream()), "dhgn_msg_agg_fwd")
@@ -148,7 +176,7 @@ def msg_agg(p, q, e, adj, W, b, adj_mode=ADJ_TENSOR, kvalid=None, q_div=1):
     """sum_j abar_ij ReLU(W [p_i - q_j, p_i - e] + b): DHGN.coordinate/message/mean_operator fused
     (reference DHGN/mappo_parallel.py:235-239, 323-334, 346-347).  p (R,P,4), q (R/q_div,K,4), e (R,4)|None,
     adj (R,P,K)|None -> (R,P,E)."""
-    return _MsgAgg.apply(p, q, e, adj if adj_mode == ADJ_TENSOR else None, kvalid if adj_mode == ADJ_VALID else None, W, b,
+    return _MsgAgg.apply(p, q, e, adj if adj_mode in (ADJ_TENSOR, ADJ_BITS) else None, kvalid if adj_mode == ADJ_VALID else None, W, b,
                          adj_mode, q_div)
 
 
@@ -196,6 +224,8 @@ def msg_agg3(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, is_critic, o_
     """(R, P, 3, E): the message/aggregate of the defender, evader and obstacle relation (DHGN/mappo_parallel.py:256-281)."""
     mode = ADJ_ONES if is_critic else ADJ_TENSOR
     mode_o = ADJ_VALID if (is_critic and o_kvalid is not None) else mode
+    if mode_o == ADJ_TENSOR and adj_o.dtype == torch.int32:  # bit-packed LiDAR rows (env o_adj_bits): same results, 1/29 of the bytes
+        mode_o = ADJ_BITS
     return _MsgAgg3.apply(p, e, o, adj_p, adj_e, adj_o, o_kvalid if mode_o == ADJ_VALID else None, W0, b0, W1, b1, W2, b2, mode,
                           mode_o, q_div)
 

@@ -35,7 +35,7 @@ class PeState(C.Structure):
 class PeObsOut(C.Structure):
     _fields_ = [("p_state", C.c_void_p), ("p_state_stride", C.c_int64), ("e_state", C.c_void_p), ("e_state_stride", C.c_int64),
                 ("p_adj", C.c_void_p), ("p_adj_stride", C.c_int64), ("e_adj", C.c_void_p), ("e_adj_stride", C.c_int64),
-                ("o_adj", C.c_void_p), ("o_adj_stride", C.c_int64)]
+                ("o_adj", C.c_void_p), ("o_adj_stride", C.c_int64), ("o_adj_bits", C.c_void_p), ("o_adj_bits_stride", C.c_int64)]
 
 
 class PeStepOut(C.Structure):
@@ -238,18 +238,25 @@ class BatchedEnv:
         self.t_host = 0
 
     # -- observation / step entry points -----------------------------------------------------------------
-    def new_obs(self):
+    def new_obs(self, packed=False):
+        """fp32 observation tensors in the reference's layouts; packed=True: the LiDAR rows as `o_adj_bits` (N, P, RW) int32
+        (bit k of row i = o_adj[i][k]) instead of the (N, P, O) float `o_adj` -- the form the product's rollout consumes."""
         c, N, dev = self.c, self.N, self.device
         f = lambda *s: torch.empty((N, *s), dtype=torch.float32, device=dev)
-        return dict(p_state=f(c.P, 4), e_state=f(1, 4), p_adj=f(c.P, c.P), e_adj=f(c.P, 1), o_adj=f(c.P, c.O))
+        obs = dict(p_state=f(c.P, 4), e_state=f(1, 4), p_adj=f(c.P, c.P), e_adj=f(c.P, 1))
+        if packed:
+            obs["o_adj_bits"] = torch.zeros((N, c.P, raser_row_words(c.O)), dtype=torch.int32, device=dev)
+        else:
+            obs["o_adj"] = f(c.P, c.O)
+        return obs
 
     @staticmethod
     def _obs_struct(obs):
         o = PeObsOut()
-        for k in ("p_state", "e_state", "p_adj", "e_adj", "o_adj"):
+        for k in ("p_state", "e_state", "p_adj", "e_adj", "o_adj", "o_adj_bits"):
             t = obs.get(k) if obs else None
             if t is not None:
-                assert t.dtype == torch.float32 and t[0].is_contiguous(), k
+                assert t.dtype == (torch.int32 if k == "o_adj_bits" else torch.float32) and t[0].is_contiguous(), k
                 setattr(o, k, t.data_ptr())
                 setattr(o, k + "_stride", t.stride(0))
         return o

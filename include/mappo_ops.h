@@ -19,7 +19,10 @@ extern "C" {
 /* adjacency source of dhgn_msg_agg_* */
 enum { MO_ADJ_TENSOR = 0,   /* actor: the observed adjacency                                            */
        MO_ADJ_ONES = 1,     /* critic: torch.ones_like(adj) over all K neighbours (AttributeDataset, :64-65) */
-       MO_ADJ_VALID = 2 };  /* critic in a batched rollout: ones over the first kvalid[row] real neighbours  */
+       MO_ADJ_VALID = 2,    /* critic in a batched rollout: ones over the first kvalid[row] real neighbours  */
+       MO_ADJ_BITS = 3 };   /* actor, 0/1 adjacency bit-packed: adj is uint32 [R][P][MO_ADJ_ROW_WORDS(K)], bit j of row i =
+                               adj[i][j] (the env's o_adj_bits, include/pe_env.h); identical results to MO_ADJ_TENSOR  */
+#define MO_ADJ_ROW_WORDS(K) (((((K) + 31) >> 5) + 3) & ~3)
 
 /*
  * Vertex-level message + mean aggregation of one DHGN relation, never materialising the (R,P,K,E) message:
@@ -30,12 +33,12 @@ enum { MO_ADJ_TENSOR = 0,   /* actor: the observed adjacency                    
  *   R rows, P agents, K neighbours, E features (multiple of 64, <= 256), din in {4, 8};
  *   p [R][P][4] (rows p_row_stride elements apart, likewise e and adj: rows may be slices buffer[:, t] of (N,T,..)
  *   replay-buffer tensors); q [R/q_div][K][4] (q_div p-rows share one q-row: obstacles are static over an episode);
- *   e [R][4] or NULL (din == 4); adj [R][P][K] (MO_ADJ_TENSOR) ; kvalid [R/q_div] (MO_ADJ_VALID);
+ *   e [R][4] or NULL (din == 4); adj [R][P][K] float (MO_ADJ_TENSOR) or packed words (MO_ADJ_BITS); kvalid [R/q_div] (MO_ADJ_VALID);
  *   W [E][din]; b [E]; out [R][P][E] with out_stride elements between consecutive [E] vectors (out_stride = 3E
  *   writes relation r of an [R][P][3][E] tensor when out points at slot r).
  */
 int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_row_stride,
-                     const float *q, int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const float *adj,
+                     const float *q, int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const void *adj,
                      int64_t adj_row_stride, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
                      float *out, int64_t out_stride /* elements between consecutive (row, agent) vectors, >= E */, void *stream);
 
@@ -47,7 +50,7 @@ int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
  */
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din);
 int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_row_stride,
-                     const float *q, int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const float *adj,
+                     const float *q, int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const void *adj,
                      int64_t adj_row_stride, int32_t adj_mode, const int32_t *kvalid, const float *W, const float *b,
                      const float *gout, int64_t gout_stride, float *dW, float *db, void *workspace, void *stream);
 

@@ -94,6 +94,9 @@ typedef struct pe_obs_out {
     float *p_adj;   int64_t p_adj_stride;    /* [N][P][P]  communicate() incl. its column-1 quirk */
     float *e_adj;   int64_t e_adj_stride;    /* [N][P][1]  find_attacker()                        */
     float *o_adj;   int64_t o_adj_stride;    /* [N][P][O]  LiDAR row, zero padded to O            */
+    /* the same LiDAR rows bit-packed (bit k of row i = o_adj[i][k]), PE_RASER_ROW_WORDS(O) words per row: 1/29 of the bytes.
+     * The product's rollout / replay buffer / msg-agg kernels consume this form (MO_ADJ_BITS); o_adj stays the reference layout. */
+    uint32_t *o_adj_bits; int64_t o_adj_bits_stride;   /* [N][P][RW] */
 } pe_obs_out;
 
 typedef struct pe_step_out {

@@ -17,12 +17,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="cfg2")
 ap.add_argument("--num-envs", type=int, default=4096)
 ap.add_argument("--episodes", type=int, default=1)
+ap.add_argument("--float-obs", action="store_true", help="request the fp32 (N, P, O) o_adj rows instead of the packed rows the rollout uses")
 args = ap.parse_args()
 cfg = baseline_config(args.config, **{"runtime.num_envs": args.num_envs})
 env = Pursuit_Env(cfg, num_envs=args.num_envs)
 env.sim.overlap_replan = False  # one stream: per-kernel durations
 N, P, T = env.num_envs, env.num_defender, env.max_steps
-obs = env.sim.new_obs()
+obs = env.sim.new_obs(packed=not args.float_obs)
 reward = torch.zeros((N, P), dtype=torch.float32, device="cuda")
 g = torch.Generator(device="cuda").manual_seed(0)
 for ep in range(args.episodes):
