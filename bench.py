@@ -65,36 +65,50 @@ def load_pmc_traffic(N, us_live):
 
 
 def measure_env_tick(trainer, n_ticks, packed=True):
-    """Launch durations of the fused env tick (HIP events on the launch stream; random actions, policy excluded):
-    the regular tick and the replan variant that runs every `difficulty` ticks; plus the A* work of the last replan.
-    packed: the LiDAR rows leave the kernel bit-packed (what the rollout consumes) or as the reference's fp32 (N, P, O) rows."""
+    """Launch durations of the fused env tick, HIP events on the launch stream (random actions, policy excluded).
+    Regular ticks: the D-1 launches between two replans are captured once as a hipGraph and replayed, so the events bracket
+    back-to-back launches with no host time in between (the Python launch path costs more than the 11 us kernel); the figure
+    is elapsed / launches, i.e. the kernel plus its ~1 us same-stream kernel boundary.  Replan ticks (every `difficulty`
+    ticks, ~1 ms) are launched eagerly.  packed: LiDAR rows leave the kernel bit-packed (what the rollout consumes) or as
+    the reference's fp32 (N, P, O) rows."""
     import torch
     env = trainer.env
+    sim = env.sim
     N, P, D = env.num_envs, env.num_defender, env.pe_cfg.difficulty
     env.reset()
-    overlap, env.sim.overlap_replan = env.sim.overlap_replan, False  # per-kernel durations: keep everything on one stream
-    obs = env.sim.new_obs(packed=packed)
+    overlap, sim.overlap_replan = sim.overlap_replan, False  # per-kernel durations: keep everything on one stream
+    obs = sim.new_obs(packed=packed)
     reward = torch.zeros((N, P), dtype=torch.float32, device=trainer.device)
-    acts = torch.randint(0, 9, (n_ticks, N, P), dtype=torch.int32, device=trainer.device)
+    acts = torch.randint(0, 9, (D, N, P), dtype=torch.int32, device=trainer.device)
     env.observe(obs)
     env.attacker_step()
     torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_ticks + 1)]
+    t_host0, time_step0 = sim.t_host, env.time_step
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):        # the D-1 regular ticks that follow a replan tick (t_host = 1 .. D-1)
+        for k in range(D - 1):
+            env.tick(acts[k], obs, reward)
+    sim.t_host, env.time_step = t_host0, time_step0   # capture only recorded the launches
+    blocks = max(1, n_ticks // D)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * blocks + 1)]
     ev[0].record()
-    kinds = []
-    for t in range(n_ticks):
-        env.tick(acts[t], obs, reward)
-        kinds.append(env.sim.t_host % D == 0)
-        ev[t + 1].record()
+    for b in range(blocks):
+        graph.replay()
+        sim.t_host += D - 1
+        env.time_step += D - 1
+        ev[2 * b + 1].record()
+        env.tick(acts[D - 1], obs, reward)      # t_host becomes a multiple of D: the replan variant
+        assert sim.t_host % D == 0
+        ev[2 * b + 2].record()
     torch.cuda.synchronize()
-    env.sim.overlap_replan = overlap
-    dur = [ev[t].elapsed_time(ev[t + 1]) * 1e-3 for t in range(n_ticks)]
-    reg = [d for d, k in zip(dur, kinds) if not k]
-    rep = [d for d, k in zip(dur, kinds) if k]
-    exp = env.sim.meta[:, 5].float()
-    return dict(regular=sum(reg) / max(1, len(reg)), replan=(sum(rep) / len(rep) if rep else float("nan")),
-                replan_max=max(rep) if rep else float("nan"), avg=sum(dur) / n_ticks,
-                astar_exp_mean=float(exp.mean()), astar_exp_max=float(exp.max()))
+    sim.overlap_replan = overlap
+    reg = [ev[2 * b].elapsed_time(ev[2 * b + 1]) * 1e-3 / (D - 1) for b in range(blocks)]
+    rep = [ev[2 * b + 1].elapsed_time(ev[2 * b + 2]) * 1e-3 for b in range(blocks)]
+    exp = sim.meta[:, 5].float()
+    if int(sim.status().max()):
+        raise RuntimeError("environment kernel status bits set during the tick measurement")
+    return dict(regular=sum(reg) / len(reg), replan=sum(rep) / len(rep), replan_max=max(rep),
+                avg=(sum(reg) * (D - 1) + sum(rep)) / (blocks * D), astar_exp_mean=float(exp.mean()), astar_exp_max=float(exp.max()))
 
 
 def measure_compute_kernels(trainer, cfg):
@@ -229,6 +243,12 @@ def cpu_baseline(config, T, envs_per_proc=4):
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
+    # torch's autograd engine opens the GPU on the first backward() of ANY process of a ROCm build (device-count query); the
+    # workers are CPU processes and the box admits few processes with the device open: oracle/nogpu_shim.c answers that query
+    shim = os.path.join(ROOT, "oracle", "libnogpu_shim.so")
+    if not os.path.exists(shim):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libnogpu_shim.so"], stdout=subprocess.DEVNULL)
+    env["LD_PRELOAD"] = shim + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", config, str(envs_per_proc), str(T), str(1000 * (i + 1))],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT) for i in range(cores)]
     res = []

@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int PE_TAPE_LDS = 32;   // tape entries kept in LDS (longer tapes fall back to a global read)
+constexpr int PE_TAPE_LDS = 32;   // tape entries prefetched with the first batch of loads (longer tapes: a second, looped copy)
 constexpr int PE_WP_WINDOW = 16;  // waypoints kept next to the meta record (>= pops between two replans)
 constexpr double SQRT2 = 0x1.6a09e667f3bcdp+0;  // math.hypot(1, 1)  (astar.py:96)
 
@@ -116,7 +116,7 @@ __device__ __forceinline__ void wave_argmin_f(double &f, unsigned int &sel) {
 struct Lds {
     uint8_t *grid;   // [W*H]
     double *def;     // [4][P]
-    double *prop;    // [4][P]
+    double *prop;    // [4][P] + [6]: the evader's desired velocity (2) and proposed state (4) of the merged tick
     double *eva;     // [4]
     uint32_t *rw;    // [P][raser_row_words(O)]  LiDAR rows (hit bits) of the defenders' cells
     uint8_t *cond;   // [P*P]
@@ -128,11 +128,11 @@ struct Lds {
     uint16_t *olist; // [(W+1)*(H+1)]  compact OPEN list (unordered)
     double *g;       // [(W+1)*(H+1)]
     // copies of the small per-environment records, prefetched with the grids in ONE batch of global loads at kernel start
-    int32_t *m;      // [PE_META_INTS] meta | [PE_MAX_P] actions | [2] target | [2*PE_TAPE_LDS] tape | [PE_WP_WINDOW] waypoints
+    int32_t *m;      // [PE_META_INTS] meta | [PE_MAX_P] actions | [2] target | [PE_WP_WINDOW] waypoints | [2*tape_len] tape (whole)
     __device__ __forceinline__ int32_t *acts() const { return m + PE_META_INTS; }
     __device__ __forceinline__ int32_t *tg() const { return m + PE_META_INTS + PE_MAX_P; }
-    __device__ __forceinline__ int32_t *tp() const { return m + PE_META_INTS + PE_MAX_P + 2; }
-    __device__ __forceinline__ uint32_t *wp() const { return (uint32_t *)(m + PE_META_INTS + PE_MAX_P + 2 + 2 * PE_TAPE_LDS); }
+    __device__ __forceinline__ uint32_t *wp() const { return (uint32_t *)(m + PE_META_INTS + PE_MAX_P + 2); }
+    __device__ __forceinline__ int32_t *tp() const { return m + PE_META_INTS + PE_MAX_P + 2 + PE_WP_WINDOW; }
     double *rnl;     // [1 + 2P]  reward normaliser
 };
 
@@ -145,13 +145,13 @@ __host__ __device__ inline size_t lds_layout(const pe_config &c, bool with_obs, 
     size_t o_g = take(sizeof(double) * (with_replan ? NN : 0));
     size_t o_rnl = take(sizeof(double) * (1 + 2 * PE_MAX_P));
     size_t o_def = take(sizeof(double) * 4 * P);
-    size_t o_prop = take(sizeof(double) * 4 * P);
+    size_t o_prop = take(sizeof(double) * (4 * P + 6));
     size_t o_eva = take(sizeof(double) * 4);
     size_t o_rw = take(with_obs ? sizeof(uint32_t) * P * raser_row_words(c.O) : 0);
     size_t o_misc = take(sizeof(int32_t) * (8 + 2 * PE_MAX_P));
     size_t o_parent = take(sizeof(uint16_t) * (with_replan ? NN : 0));
     size_t o_olist = take(sizeof(uint16_t) * (with_replan ? NN : 0));
-    size_t o_m = take(sizeof(int32_t) * (PE_META_INTS + PE_MAX_P + 2 + 2 * PE_TAPE_LDS + PE_WP_WINDOW));
+    size_t o_m = take(sizeof(int32_t) * (PE_META_INTS + PE_MAX_P + 2 + PE_WP_WINDOW + 2 * (c.tape_len > 0 ? c.tape_len : 1)));
     size_t o_grid = take(WH);
     size_t o_cond = take(P * P);
     size_t o_obs = take(with_replan ? NN : 0);
@@ -230,18 +230,31 @@ __device__ __forceinline__ bool in_bound_i(const pe_config &c, int x, int y) { r
 // every probe of every defender in two wave instructions; the in-place semantics are then resolved on 64-bit wave masks --
 // for the (rare) out-of-box defenders b in index order: accepted(b) swaps column b of the pair mask to the clipped
 // distances for the rows behind it.  Exactly the reference's sequential result, without the P-iteration loop.
-template <bool FAST8>
+// MERGE_EVA (fused tick without replan): lane P integrates the evader's first-order lag in the SAME instructions as the
+// defenders' (agent.py:74-104 is one formula with per-agent tau / step size); its heading was computed by dev_evader_pre, its
+// proposal is consumed by dev_evader_post after the observations were taken from the old evader state.
+template <bool FAST8, bool MERGE_EVA>
 __device__ void dev_step(const pe_config &c, const SqThr &th, const Lds &l, int lane, double *def_hbm, const pe_step_out &out, int env) {
     const int P = c.P;
     int32_t *meta = l.m;
     double *rn = l.rnl;
     double o[4] = {0.0, 0.0, 0.0, 0.0};
-    if (lane < P) {
-        int a = l.acts()[lane];
-        a = a < 0 ? 0 : (a > 8 ? 8 : a);
-        dynamic(c.def_tau, th.inv_def_tau, th.inv_six, c.def_dt, l.def[lane], l.def[P + lane], l.def[2 * P + lane], l.def[3 * P + lane], c.action_u[a][0],
-                c.action_u[a][1], o);
-        l.prop[lane] = o[0]; l.prop[P + lane] = o[1]; l.prop[2 * P + lane] = o[2]; l.prop[3 * P + lane] = o[3];
+    {
+        double tau = c.def_tau, itau = th.inv_def_tau, h = c.def_dt, x = 0.0, y = 0.0, vx = 0.0, vy = 0.0, ux = 0.0, uy = 0.0;
+        const bool is_eva = MERGE_EVA && lane == P;
+        if (lane < P) {
+            int a = l.acts()[lane];
+            a = a < 0 ? 0 : (a > 8 ? 8 : a);
+            x = l.def[lane]; y = l.def[P + lane]; vx = l.def[2 * P + lane]; vy = l.def[3 * P + lane];
+            ux = c.action_u[a][0]; uy = c.action_u[a][1];
+        } else if (is_eva) {
+            tau = c.eva_tau; itau = th.inv_eva_tau; h = c.eva_dt;
+            x = l.eva[0]; y = l.eva[1]; vx = l.eva[2]; vy = l.eva[3];
+            ux = l.prop[4 * P]; uy = l.prop[4 * P + 1];
+        }
+        if (lane < P || is_eva) dynamic(tau, itau, th.inv_six, h, x, y, vx, vy, ux, uy, o);
+        if (lane < P) { l.prop[lane] = o[0]; l.prop[P + lane] = o[1]; l.prop[2 * P + lane] = o[2]; l.prop[3 * P + lane] = o[3]; }
+        if (is_eva) { l.prop[4 * P + 2] = o[0]; l.prop[4 * P + 3] = o[1]; l.prop[4 * P + 4] = o[2]; l.prop[4 * P + 5] = o[3]; }
     }
     wave_sync();
     const double r = c.def_collision_radius;
@@ -664,6 +677,69 @@ __device__ __forceinline__ uint32_t dev_waypoint(const Lds &l, const int16_t *pa
 }
 
 // ---- Pursuit_Env.attacker_step (pursuit_env.py:75-102), waypoint2phi (agent.py:261-271) -----------------
+// Three pieces on lane 0: waypoint bookkeeping + heading (pre), the lag integration (dynamic()), acceptance + target re-draw
+// (post).  dev_evader runs them back to back; the fused no-replan tick runs `pre` before the defenders' step, integrates on
+// lane P inside dev_step<.., MERGE_EVA> and runs `post` after the observations (which must see the old evader state, Q3).
+__device__ __forceinline__ void dev_evader_pre(const pe_config &c, const SqThr &th, const Lds &l, const int16_t *path, double &ux_out, double &uy_out) {
+    int32_t *meta = l.m;
+    int len = meta[PE_META_PATH_LEN], cnt = meta[PE_META_PATH_CNT], head = meta[PE_META_WP_HEAD];
+    const double ex = l.eva[0], ey = l.eva[1];
+    int status = 0;
+    if (cnt < 1) { status |= PE_STATUS_PATH_UNDERFLOW; cnt = 1; }
+    // path[cnt-1] is the next waypoint; the window holds it without a dependent global read
+    uint32_t wv = dev_waypoint(l, path, head, cnt);
+    double wx = (double)(int16_t)(wv >> 16), wy = (double)(int16_t)(wv & 0xFFFFu);
+    if (len >= 2 && norm2sq(ex - wx, ey - wy) <= th.res_lt) {
+        len--;
+        if (cnt > 1) {
+            cnt--; head++;
+            wv = dev_waypoint(l, path, head, cnt);
+            wx = (double)(int16_t)(wv >> 16); wy = (double)(int16_t)(wv & 0xFFFFu);
+        } else status |= PE_STATUS_PATH_UNDERFLOW;
+    }
+    // phi = sign(dy) * arccos(dx / (r + 1e-3)); u = vmax * (cos phi, sin phi).  cos(arccos(q)) == q and
+    // sin(arccos(q)) == sqrt((1-q)(1+q)) are used in place of libm (same form in the CPU oracle); sign(0) == 0
+    // gives phi == 0.
+    double dx = wx - ex, dy = wy - ey;
+    double radius = norm2(dx, dy);
+    double cphi = 1.0, sphi = 0.0;
+    if (!(radius <= 0.01) && dy != 0.0) {
+        double q = dx / (radius + 1e-3);
+        double s = __builtin_sqrt((1.0 - q) * (1.0 + q));
+        cphi = q;
+        sphi = dy > 0.0 ? s : -s;
+    }
+    ux_out = cphi * c.eva_vmax;
+    uy_out = sphi * c.eva_vmax;
+    meta[PE_META_PATH_LEN] = len;
+    meta[PE_META_PATH_CNT] = cnt;
+    meta[PE_META_WP_HEAD] = head;
+    if (status) meta[PE_META_STATUS] |= status;
+}
+
+__device__ __forceinline__ void dev_evader_post(const pe_config &c, const SqThr &th, const Lds &l, double ns0, double ns1, double ns2, double ns3,
+                                                int32_t *target_hbm, const int32_t *tape_hbm, double *eva_hbm) {
+    const double ns[4] = {ns0, ns1, ns2, ns3};
+    int32_t *meta = l.m;
+    int status = 0;
+    int ix = py_round(ns[0]), iy = py_round(ns[1]);
+    if (in_bound_i(c, ix, iy) && l.grid[ix * c.H + iy] == 0) {
+        l.eva[0] = ns[0]; l.eva[1] = ns[1]; l.eva[2] = ns[2]; l.eva[3] = ns[3];
+        eva_hbm[0] = ns[0]; eva_hbm[1] = ns[1]; eva_hbm[2] = ns[2]; eva_hbm[3] = ns[3];
+    }
+    // the target is re-drawn when the PROPOSED position reaches it (pursuit_env.py:98-100); draws come from the tape
+    if (norm2sq((double)l.tg()[0] - ns[0], (double)l.tg()[1] - ns[1]) <= th.evacoll_le) {
+        int pos = meta[PE_META_TAPE_POS];
+        int k = pos < c.tape_len ? pos : c.tape_len - 1;
+        if (pos >= c.tape_len) status |= PE_STATUS_TAPE_EXHAUSTED;
+        const int nx = l.tp()[2 * k], ny = l.tp()[2 * k + 1];  // the whole tape is LDS-resident
+        l.tg()[0] = nx; l.tg()[1] = ny;
+        target_hbm[0] = nx; target_hbm[1] = ny;
+        meta[PE_META_TAPE_POS] = pos + 1;
+    }
+    if (status) meta[PE_META_STATUS] |= status;
+}
+
 template <bool REPLAN>
 __device__ void dev_evader(const pe_config &c, const SqThr &th, const Lds &l, int lane, int16_t *path, uint32_t *wp_hbm, int32_t *target_hbm,
                            const int32_t *tape_hbm, double *eva_hbm) {
@@ -675,67 +751,25 @@ __device__ void dev_evader(const pe_config &c, const SqThr &th, const Lds &l, in
         }
     }
     if (lane == 0) {
-        int len = meta[PE_META_PATH_LEN], cnt = meta[PE_META_PATH_CNT], head = meta[PE_META_WP_HEAD];
-        const double ex = l.eva[0], ey = l.eva[1];
-        int status = 0;
-        if (cnt < 1) { status |= PE_STATUS_PATH_UNDERFLOW; cnt = 1; }
-        // path[cnt-1] is the next waypoint; the window holds it without a dependent global read
-        uint32_t wv = dev_waypoint(l, path, head, cnt);
-        double wx = (double)(int16_t)(wv >> 16), wy = (double)(int16_t)(wv & 0xFFFFu);
-        if (len >= 2 && norm2sq(ex - wx, ey - wy) <= th.res_lt) {
-            len--;
-            if (cnt > 1) {
-                cnt--; head++;
-                wv = dev_waypoint(l, path, head, cnt);
-                wx = (double)(int16_t)(wv >> 16); wy = (double)(int16_t)(wv & 0xFFFFu);
-            } else status |= PE_STATUS_PATH_UNDERFLOW;
-        }
-        // phi = sign(dy) * arccos(dx / (r + 1e-3)); u = vmax * (cos phi, sin phi).  cos(arccos(q)) == q and
-        // sin(arccos(q)) == sqrt((1-q)(1+q)) are used in place of libm (same form in the CPU oracle); sign(0) == 0
-        // gives phi == 0.
-        double dx = wx - ex, dy = wy - ey;
-        double radius = norm2(dx, dy);
-        double cphi = 1.0, sphi = 0.0;
-        if (!(radius <= 0.01) && dy != 0.0) {
-            double q = dx / (radius + 1e-3);
-            double s = __builtin_sqrt((1.0 - q) * (1.0 + q));
-            cphi = q;
-            sphi = dy > 0.0 ? s : -s;
-        }
-        double ns[4];
-        dynamic(c.eva_tau, th.inv_eva_tau, th.inv_six, c.eva_dt, ex, ey, l.eva[2], l.eva[3], cphi * c.eva_vmax, sphi * c.eva_vmax, ns);
-        int ix = py_round(ns[0]), iy = py_round(ns[1]);
-        if (in_bound_i(c, ix, iy) && l.grid[ix * c.H + iy] == 0) {
-            l.eva[0] = ns[0]; l.eva[1] = ns[1]; l.eva[2] = ns[2]; l.eva[3] = ns[3];
-            eva_hbm[0] = ns[0]; eva_hbm[1] = ns[1]; eva_hbm[2] = ns[2]; eva_hbm[3] = ns[3];
-        }
-        // the target is re-drawn when the PROPOSED position reaches it (pursuit_env.py:98-100); draws come from the tape
-        if (norm2sq((double)l.tg()[0] - ns[0], (double)l.tg()[1] - ns[1]) <= th.evacoll_le) {
-            int pos = meta[PE_META_TAPE_POS];
-            int k = pos < c.tape_len ? pos : c.tape_len - 1;
-            if (pos >= c.tape_len) status |= PE_STATUS_TAPE_EXHAUSTED;
-            int nx, ny;
-            if (k < PE_TAPE_LDS) { nx = l.tp()[2 * k]; ny = l.tp()[2 * k + 1]; } else { nx = tape_hbm[2 * k]; ny = tape_hbm[2 * k + 1]; }
-            l.tg()[0] = nx; l.tg()[1] = ny;
-            target_hbm[0] = nx; target_hbm[1] = ny;
-            meta[PE_META_TAPE_POS] = pos + 1;
-        }
-        meta[PE_META_PATH_LEN] = len;
-        meta[PE_META_PATH_CNT] = cnt;
-        meta[PE_META_WP_HEAD] = head;
-        if (status) meta[PE_META_STATUS] |= status;
+        double ux, uy, ns[4];
+        dev_evader_pre(c, th, l, path, ux, uy);
+        dynamic(c.eva_tau, th.inv_eva_tau, th.inv_six, c.eva_dt, l.eva[0], l.eva[1], l.eva[2], l.eva[3], ux, uy, ns);
+        dev_evader_post(c, th, l, ns[0], ns[1], ns[2], ns[3], target_hbm, tape_hbm, eva_hbm);
     }
     wave_sync();
 }
 
-template <bool STEP, bool OBS, bool EVA, bool REPLAN, bool FAST8>
-__global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state st, const int32_t *actions, const pe_step_out sout,
-                                               const pe_obs_out oout, const SqThr th) {
+// WPB wavefronts (= environments) per workgroup: the waves of a workgroup never synchronise with each other (wave_sync only),
+// a fatter workgroup just lets the dispatcher start the grid in a quarter of the time (4096 one-wave workgroups take ~2.7 us
+// to start, first to last; the whole tick runs ~12).  The replan variant keeps one wave per workgroup (30 KB of LDS each).
+template <bool STEP, bool OBS, bool EVA, bool REPLAN, bool FAST8, int WPB>
+__global__ __launch_bounds__(WAVE * WPB) void k_tick(const pe_config c, const pe_state st, const int32_t *actions, const pe_step_out sout,
+                                                     const pe_obs_out oout, const SqThr th, const int lds_per_env) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int env = blockIdx.x, lane = threadIdx.x;
+    const int env = blockIdx.x * WPB + (WPB > 1 ? (int)(threadIdx.x >> 6) : 0), lane = threadIdx.x & (WAVE - 1);
     if (env >= st.N) return;
     Lds l;
-    lds_layout(c, OBS, EVA && REPLAN, smem, &l);
+    lds_layout(c, OBS, EVA && REPLAN, smem + (WPB > 1 ? (size_t)(threadIdx.x >> 6) * lds_per_env : 0), &l);
     const int WH = c.W * c.H, P = c.P;
     double *def_hbm = st.def + (size_t)env * 4 * P;
     double *eva_hbm = st.eva + (size_t)env * 4;
@@ -781,10 +815,26 @@ __global__ __launch_bounds__(WAVE) void k_tick(const pe_config c, const pe_state
     if (STEP && lane < 1 + 2 * P) l.rnl[lane] = r_rn;
     if (EVA && lane < PE_WP_WINDOW) l.wp()[lane] = r_wp;
     if (EVA && lane < 2 * c.tape_len && lane < 2 * PE_TAPE_LDS) l.tp()[lane] = r_tp;
+    if (EVA && c.tape_len > PE_TAPE_LDS) for (int i = 2 * PE_TAPE_LDS + lane; i < 2 * c.tape_len; i += WAVE) l.tp()[i] = tape_hbm[i];
     wave_sync();
-    if (STEP) dev_step<FAST8>(c, th, l, lane, def_hbm, sout, env);
+    constexpr bool MERGE_EVA = STEP && EVA && !REPLAN;  // the evader's lag integration rides on lane P of the defenders' step
+    int16_t *path = st.path + (size_t)env * c.max_path * 2;
+    if (MERGE_EVA) {
+        if (lane == 0) {
+            double ux, uy;
+            dev_evader_pre(c, th, l, path, ux, uy);
+            l.prop[4 * P] = ux; l.prop[4 * P + 1] = uy;
+        }
+        wave_sync();
+    }
+    if (STEP) dev_step<FAST8, MERGE_EVA>(c, th, l, lane, def_hbm, sout, env);
     if (OBS) dev_observe<FAST8>(c, th, l, lane, env, oout, st.raser + (size_t)env * WH * raser_row_words(c.O));
-    if (EVA) dev_evader<REPLAN>(c, th, l, lane, st.path + (size_t)env * c.max_path * 2, wp_hbm, target_hbm, tape_hbm, eva_hbm);
+    if (MERGE_EVA) {
+        if (lane == 0) dev_evader_post(c, th, l, l.prop[4 * P + 2], l.prop[4 * P + 3], l.prop[4 * P + 4], l.prop[4 * P + 5], target_hbm, tape_hbm, eva_hbm);
+        wave_sync();
+    } else if (EVA) {
+        dev_evader<REPLAN>(c, th, l, lane, path, wp_hbm, target_hbm, tape_hbm, eva_hbm);
+    }
     // ---- write the small records back (def / eva / target were written where they changed)
     if ((STEP || EVA) && lane < PE_META_INTS) meta_hbm[lane] = l.m[lane];
     if (STEP && c.use_reward_norm && lane < 1 + 2 * P) rn_hbm[lane] = l.rnl[lane];
@@ -925,10 +975,11 @@ uint32_t div_magic20(uint32_t d, uint32_t n) {
     return M;
 }
 
-template <bool STEP, bool OBS, bool EVA, bool REPLAN, bool FAST8>
-int launch2(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
-    size_t lds = lds_layout(*cfg, OBS, EVA && REPLAN, nullptr, nullptr);
-    auto kern = k_tick<STEP, OBS, EVA, REPLAN, FAST8>;
+template <bool STEP, bool OBS, bool EVA, bool REPLAN, bool FAST8, int WPB>
+int launch3(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
+    const size_t lds_env = align16(lds_layout(*cfg, OBS, EVA && REPLAN, nullptr, nullptr));
+    const size_t lds = lds_env * WPB;
+    auto kern = k_tick<STEP, OBS, EVA, REPLAN, FAST8, WPB>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -951,8 +1002,17 @@ int launch2(const pe_config *cfg, const pe_state *st, const int32_t *actions, co
     th.rw_shift = -1;
     for (int sft = 0; sft < 16; sft++)
         if ((1 << sft) == rw) th.rw_shift = sft;
-    hipLaunchKernelGGL(kern, dim3(st->N), dim3(WAVE), lds, (hipStream_t)stream, *cfg, *st, actions, so ? *so : s0, oo ? *oo : o0, th);
+    hipLaunchKernelGGL(kern, dim3((st->N + WPB - 1) / WPB), dim3(WAVE * WPB), lds, (hipStream_t)stream, *cfg, *st, actions, so ? *so : s0, oo ? *oo : o0, th,
+                       (int)lds_env);
     return (int)hipGetLastError();
+}
+
+template <bool STEP, bool OBS, bool EVA, bool REPLAN, bool FAST8>
+int launch2(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *so, const pe_obs_out *oo, void *stream) {
+    // four environments per workgroup unless the per-environment LDS is large (replan scratch, very large maps)
+    const bool fat = !(EVA && REPLAN) && 4 * align16(lds_layout(*cfg, OBS, false, nullptr, nullptr)) <= 48 * 1024;
+    return fat ? launch3<STEP, OBS, EVA, REPLAN, FAST8, (EVA && REPLAN) ? 1 : 4>(cfg, st, actions, so, oo, stream)
+               : launch3<STEP, OBS, EVA, REPLAN, FAST8, 1>(cfg, st, actions, so, oo, stream);
 }
 
 template <bool STEP, bool OBS, bool EVA, bool REPLAN>

@@ -29,3 +29,5 @@ pe_oracle.lib()
 fds("oracle")
 x = torch.multinomial(torch.ones(4, 9) / 9, 1)
 fds("multinomial")
+w = torch.nn.Parameter(torch.ones(3)); (w * 2).sum().backward()
+fds("first backward()")

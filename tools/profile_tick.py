@@ -46,6 +46,24 @@ for ep in range(args.episodes):
           f"{sum(rep) / max(1, len(rep)):.1f} us avg, {max(rep) if rep else 0:.1f} max; all ticks {sum(dur) / len(dur):.2f} us avg; "
           f"status bits {int(env.sim.status().max())}, mean A* expansions {float(env.sim.meta[:, 5].float().mean()):.1f}")
 
+# regular ticks replayed from a hipGraph: back-to-back launches without the Python launch path in between
+env.reset(); env.observe(obs); env.attacker_step(); torch.cuda.synchronize()
+D = env.pe_cfg.difficulty
+t0, ts0 = env.sim.t_host, env.time_step
+g9 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g9):
+    for k in range(D - 1):
+        env.tick(acts[k], obs, reward)
+env.sim.t_host, env.time_step = t0, ts0
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+tot = 0.0
+for rep in range(10):
+    e0.record(); g9.replay(); e1.record(); torch.cuda.synchronize()
+    tot += e0.elapsed_time(e1)
+    env.sim.t_host += D - 1
+    env.tick(acts[D - 1], obs, reward)
+print(f"graph-replayed regular ticks: {tot / 10 / (D - 1) * 1e3:.2f} us per launch (kernel + same-stream boundary)")
+
 # per-phase launches (each pays its own prologue): step only, observe only, evader only (no replan)
 def timeit(fn, n=40):
     fn(); torch.cuda.synchronize()
