@@ -13,6 +13,7 @@ LIBS = {
     "libpe_env.so": (["pe_env.hip", "pe_reset.cpp"], ["-ffp-contract=off", "-pthread"]),
     "libmappo_ops.so": (["mappo_ops.hip"], []),
     "libn2n_env.so": (["n2n_env.hip"], ["-ffp-contract=off", "-pthread"]),
+    "libe3d_env.so": (["e3d_env.hip"], ["-ffp-contract=off", "-pthread"]),
 }
 
 

@@ -1,6 +1,7 @@
 // n2n_env.hip -- batched env_n2n (continuous 2-D pursuit, no obstacles) for MI355X (gfx950).  C ABI: include/n2n_env.h.
-// One wavefront per environment, lane = pursuer; the environment's record (5 x (P + E) doubles) is contiguous in HBM and
-// staged in LDS; all pairwise kill-radius / range tests run out of LDS.  f64 state like the reference; headings go through
+// Several environments per wavefront (lane = (environment, agent slot), see k_n2n); the environment's record (5 x (P + E)
+// doubles) is contiguous in HBM, every agent lives in its lane's registers, pairwise kill-radius / range tests go through
+// wave shuffles.  f64 state like the reference; headings go through
 // the device cos/sin (agreement with the reference's libm: <= 1e-9 on positions over an episode, see tests).
 // Build with -ffp-contract=off; the only fused multiply-add is the explicit one in norm2 (numpy's 2-vector norm).
 #include <hip/hip_runtime.h>
@@ -34,108 +35,112 @@ __device__ __forceinline__ double turn(double a, double phi, double lim) {
 }
 __device__ __forceinline__ double wrap(double phi) { return phi > PI ? phi - 2 * PI : (phi < -PI ? phi + 2 * PI : phi); }
 
-struct Lds { double *p, *e; };  // p: [5][P], e: [5][E]
+// lane = (environment, agent slot): a group of PT lanes owns one environment (PT = power of two >= max(P, E)), G = 64 / PT
+// environments per wavefront, four wavefronts per workgroup.  Slot a holds pursuer a (a < P) AND evader a (a < E) in
+// registers; partners are read through wave shuffles inside the group.  (One wavefront per environment left 48 of 64 lanes
+// idle at P = 16 and the launch bound by per-wave latency: 9 % of the HBM roofline in round 1.)
+constexpr int WPB = 4;
 
-__device__ void dev_observe(const n2n_config &c, const Lds &l, int lane, int env, const n2n_obs_out &o) {
-    const int P = c.P, E = c.E;
-    if (o.p_state) for (int i = lane; i < 3 * P; i += WAVE) o.p_state[(int64_t)env * o.p_state_stride + i] = (float)l.p[(i % 3) * P + i / 3];
-    if (o.e_state) for (int i = lane; i < 3 * E; i += WAVE) o.e_state[(int64_t)env * o.e_state_stride + i] = (float)l.e[(i % 3) * E + i / 3];
-    if (o.pp_adj)
-        for (int idx = lane; idx < P * P; idx += WAVE) {
-            const int i = idx / P, j = idx - i * P;
-            const bool v = l.p[4 * P + i] != 0.0 && norm2(l.p[i] - l.p[j], l.p[P + i] - l.p[P + j]) <= c.p_comm_range;
-            o.pp_adj[(int64_t)env * o.pp_adj_stride + idx] = v ? 1.f : 0.f;
-        }
-    if (o.pe_adj)
-        for (int idx = lane; idx < P * E; idx += WAVE) {
-            const int i = idx / E, j = idx - i * E;
-            const bool v = l.p[4 * P + i] != 0.0 && norm2(l.p[i] - l.e[j], l.p[P + i] - l.e[E + j]) <= c.p_sen_range;
-            o.pe_adj[(int64_t)env * o.pe_adj_stride + idx] = v ? 1.f : 0.f;
-        }
-}
-
-template <bool TICK>
-__global__ __launch_bounds__(WAVE) void k_n2n(const n2n_config c, const n2n_state st, const int32_t *actions, const double *e_cmd, float *reward,
-                                              uint8_t *active, uint8_t *done, const n2n_obs_out o) {
-    __shared__ double sp[5 * N2N_MAX_P], se[5 * N2N_MAX_E];
-    __shared__ uint8_t pdie[N2N_MAX_P], edie[N2N_MAX_E];
-    const int env = blockIdx.x, lane = threadIdx.x;
-    if (env >= st.N) return;
-    const int P = c.P, E = c.E;
-    double *gp = st.p + (size_t)env * 5 * P, *ge = st.e + (size_t)env * 5 * E;
-    for (int i = lane; i < 5 * P; i += WAVE) sp[i] = gp[i];
-    for (int i = lane; i < 5 * E; i += WAVE) se[i] = ge[i];
-    __syncthreads();
-    Lds l{sp, se};
+template <int PT, bool TICK>
+__global__ __launch_bounds__(WAVE * WPB) void k_n2n(const n2n_config c, const n2n_state st, const int32_t *actions, const double *e_cmd, float *reward,
+                                                    uint8_t *active, uint8_t *done, const n2n_obs_out o) {
+    constexpr int G = WAVE / PT;
+    constexpr unsigned long long GM = (PT == 64) ? ~0ull : ((1ull << PT) - 1ull);
+    const int lane = threadIdx.x & (WAVE - 1), wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int g = lane / PT, a = lane - g * PT, base = lane - a;
+    const int env = wave * G + g, P = c.P, E = c.E;
+    const bool ev = env < st.N, pv = ev && a < P, evv = ev && a < E;
+    double px = 0, py = 0, pphi = 0, pvel = 0, pact = 0, ex = 0, ey = 0, ephi = 0, evel = 0, eact = 0;
+    double *gp = st.p + (size_t)(ev ? env : 0) * 5 * P, *ge = st.e + (size_t)(ev ? env : 0) * 5 * E;
+    if (pv) { px = gp[a]; py = gp[P + a]; pphi = gp[2 * P + a]; pvel = gp[3 * P + a]; pact = gp[4 * P + a]; }
+    if (evv) { ex = ge[a]; ey = ge[E + a]; ephi = ge[2 * E + a]; evel = ge[3 * E + a]; eact = ge[4 * E + a]; }
     if (TICK) {
-        const double tx = st.target[2 * env], ty = st.target[2 * env + 1];
         // Evader.step (:74-99): position with the OLD heading, then the heading turns towards the command
-        if (lane < E && se[4 * E + lane] != 0.0) {
-            const double phi = se[2 * E + lane], v = se[3 * E + lane];
-            const double d = turn(e_cmd[(size_t)env * E + lane] * PI, phi, c.ang_lmt);
-            se[lane] += v * cos(phi) * c.step_size;
-            se[E + lane] += v * sin(phi) * c.step_size;
-            se[2 * E + lane] = wrap(phi + d);
+        if (evv && eact != 0.0) {
+            const double d = turn(e_cmd[(size_t)env * E + a] * PI, ephi, c.ang_lmt);
+            ex += evel * cos(ephi) * c.step_size;
+            ey += evel * sin(ephi) * c.step_size;
+            ephi = wrap(ephi + d);
         }
         // Pursuer.step (:34-67): the heading turns even when the pursuer is inactive, the position only moves when active
-        if (lane < P) {
-            const int a_i = actions[(size_t)env * P + lane];
-            double v = 0.0, phi = sp[2 * P + lane];
+        if (pv) {
+            const int a_i = actions[(size_t)env * P + a];
+            double v = 0.0;
             if (a_i != 0) {
                 v = c.p_vmax;
-                double a = (double)a_i * PI / 4;
-                if (a > PI) a -= 2 * PI;
-                phi = wrap(phi + turn(a, phi, c.ang_lmt));
-                sp[2 * P + lane] = phi;
+                double ang = (double)a_i * PI / 4;
+                if (ang > PI) ang -= 2 * PI;
+                pphi = wrap(pphi + turn(ang, pphi, c.ang_lmt));
             }
-            if (sp[4 * P + lane] != 0.0) {
-                sp[lane] += v * cos(phi) * c.step_size;
-                sp[P + lane] += v * sin(phi) * c.step_size;
-                sp[3 * P + lane] = v;
+            if (pact != 0.0) {
+                px += v * cos(pphi) * c.step_size;
+                py += v * sin(pphi) * c.step_size;
+                pvel = v;
             }
         }
-        __syncthreads();
         // reward (:316-334) and update_agent_active (:336-365) are both evaluated on the moved, not yet culled state
-        if (lane < P) {
-            float r = 0.f;
-            bool die = false;
-            if (sp[4 * P + lane] != 0.0) {
-                int ce = 0, cp = 0;
-                for (int k = 0; k < E; k++) ce += se[4 * E + k] != 0.0 && norm2(sp[lane] - se[k], sp[P + lane] - se[E + k]) <= c.kill_radius;
-                for (int k = 0; k < P; k++) cp += sp[4 * P + k] != 0.0 && norm2(sp[lane] - sp[k], sp[P + lane] - sp[P + k]) <= c.kill_radius;
-                r = (float)(ce - (cp - 1));
-                die = (cp + ce - 1) != 0;
-            }
-            reward[(size_t)env * P + lane] = r;
-            pdie[lane] = die;
+        int ce = 0, cp = 0, chit = 0;
+        for (int k = 0; k < E; k++) {
+            const double kx = __shfl(ex, base + k), ky = __shfl(ey, base + k), ka = __shfl(eact, base + k);
+            ce += ka != 0.0 && norm2(px - kx, py - ky) <= c.kill_radius;
         }
-        if (lane < E) {
-            bool die = false;
-            if (se[4 * E + lane] != 0.0) {
-                int cnt = 0;
-                for (int i = 0; i < P; i++) cnt += sp[4 * P + i] != 0.0 && norm2(se[lane] - sp[i], se[E + lane] - sp[P + i]) <= c.kill_radius;
-                die = cnt != 0;
-            }
-            edie[lane] = die;
+        for (int k = 0; k < P; k++) {
+            const double kx = __shfl(px, base + k), ky = __shfl(py, base + k), ka = __shfl(pact, base + k);
+            cp += ka != 0.0 && norm2(px - kx, py - ky) <= c.kill_radius;
+            chit += ka != 0.0 && norm2(ex - kx, ey - ky) <= c.kill_radius;   // the evader of this slot against pursuer k
         }
-        __syncthreads();
-        if (lane < P && pdie[lane]) { sp[lane] = 1000; sp[P + lane] = 1000; sp[2 * P + lane] = 0; sp[4 * P + lane] = 0; }
-        if (lane < E && edie[lane]) { se[lane] = 1000; se[E + lane] = 1000; se[2 * E + lane] = 0; se[4 * E + lane] = 0; }
-        __syncthreads();
-        const bool pact = lane < P && sp[4 * P + lane] != 0.0;
-        const bool eact = lane < E && se[4 * E + lane] != 0.0;
-        const bool reach = lane < E && norm2(se[lane] - tx, se[E + lane] - ty) <= c.kill_radius;  // get_done (:283-304), all evaders
-        const int pa = __popcll(__ballot(pact)), ea = __popcll(__ballot(eact)), rc = __ballot(reach) != 0ull;
-        if (lane < P) active[(size_t)env * P + lane] = pact;
-        if (lane == 0) {
+        const bool p_on = pv && pact != 0.0, e_on = evv && eact != 0.0;
+        if (pv) reward[(size_t)env * P + a] = p_on ? (float)(ce - (cp - 1)) : 0.f;
+        if (p_on && (cp + ce - 1) != 0) { px = 1000; py = 1000; pphi = 0; pact = 0; }
+        if (e_on && chit != 0) { ex = 1000; ey = 1000; ephi = 0; eact = 0; }
+        const bool pact_b = pv && pact != 0.0, eact_b = evv && eact != 0.0;
+        double tx = 0, ty = 0;
+        if (ev) { tx = st.target[2 * env]; ty = st.target[2 * env + 1]; }
+        const bool reach = evv && norm2(ex - tx, ey - ty) <= c.kill_radius;  // get_done (:283-304), all evaders
+        const int pa = __popcll((__ballot(pact_b) >> base) & GM), ea = __popcll((__ballot(eact_b) >> base) & GM);
+        const bool rc = ((__ballot(reach) >> base) & GM) != 0ull;
+        if (pv) {
+            active[(size_t)env * P + a] = pact_b;
+            gp[a] = px; gp[P + a] = py; gp[2 * P + a] = pphi; gp[3 * P + a] = pvel; gp[4 * P + a] = pact;
+        }
+        if (evv) { ge[a] = ex; ge[E + a] = ey; ge[2 * E + a] = ephi; ge[3 * E + a] = evel; ge[4 * E + a] = eact; }
+        if (ev && a == 0) {
             const int t = st.time_step[env] + 1;
             st.time_step[env] = t;
             done[env] = (uint8_t)(rc || pa == 0 || ea == 0 || t >= c.episode_limit);
         }
-        for (int i = lane; i < 5 * P; i += WAVE) gp[i] = sp[i];
-        for (int i = lane; i < 5 * E; i += WAVE) ge[i] = se[i];
     }
-    dev_observe(c, l, lane, env, o);
+    // observations (get_team_state rules=False, get_adj_mat :386-397: rows of inactive pursuers are zero)
+    if (o.p_state && pv) {
+        float *d = o.p_state + (int64_t)env * o.p_state_stride + 3 * a;
+        d[0] = (float)px; d[1] = (float)py; d[2] = (float)pphi;
+    }
+    if (o.e_state && evv) {
+        float *d = o.e_state + (int64_t)env * o.e_state_stride + 3 * a;
+        d[0] = (float)ex; d[1] = (float)ey; d[2] = (float)ephi;
+    }
+    if (o.pp_adj)
+        for (int k = 0; k < P; k++) {  // row k, column a: the lanes of a group store consecutive floats
+            const double kx = __shfl(px, base + k), ky = __shfl(py, base + k), ka = __shfl(pact, base + k);
+            if (pv) o.pp_adj[(int64_t)env * o.pp_adj_stride + k * P + a] = (ka != 0.0 && norm2(kx - px, ky - py) <= c.p_comm_range) ? 1.f : 0.f;
+        }
+    if (o.pe_adj)
+        for (int k = 0; k < E; k++) {
+            const double kx = __shfl(ex, base + k), ky = __shfl(ey, base + k);
+            if (pv) o.pe_adj[(int64_t)env * o.pe_adj_stride + a * E + k] = (pact != 0.0 && norm2(px - kx, py - ky) <= c.p_sen_range) ? 1.f : 0.f;
+        }
+}
+
+template <bool TICK>
+int launch_n2n(const n2n_config *c, const n2n_state *st, const int32_t *actions, const double *e_cmd, float *reward, uint8_t *active, uint8_t *done,
+               const n2n_obs_out &o, hipStream_t s) {
+    const int m = c->P > c->E ? c->P : c->E;
+    const int pt = m <= 8 ? 8 : (m <= 16 ? 16 : (m <= 32 ? 32 : 64));
+    const int envs_per_block = (WAVE / pt) * WPB, blocks = (st->N + envs_per_block - 1) / envs_per_block;
+#define N2N_GO(PT) hipLaunchKernelGGL((k_n2n<PT, TICK>), dim3(blocks), dim3(WAVE * WPB), 0, s, *c, *st, actions, e_cmd, reward, active, done, o)
+    if (pt == 8) N2N_GO(8); else if (pt == 16) N2N_GO(16); else if (pt == 32) N2N_GO(32); else N2N_GO(64);
+#undef N2N_GO
+    return (int)hipGetLastError();
 }
 
 // [N][A][5] host order -> [N][5][A] records
@@ -196,9 +201,7 @@ int n2n_env_load(const n2n_config *cfg, const n2n_state *st, const double *p, co
 
 int n2n_env_observe(const n2n_config *cfg, const n2n_state *st, const n2n_obs_out *out, void *stream) {
     if (!cfg || !st || !out) return N2N_ERR_NULL;
-    hipLaunchKernelGGL(k_n2n<false>, dim3(st->N), dim3(WAVE), 0, (hipStream_t)stream, *cfg, *st, (const int32_t *)nullptr, (const double *)nullptr,
-                       (float *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, *out);
-    return (int)hipGetLastError();
+    return launch_n2n<false>(cfg, st, nullptr, nullptr, nullptr, nullptr, nullptr, *out, (hipStream_t)stream);
 }
 
 int n2n_env_tick(const n2n_config *cfg, const n2n_state *st, const int32_t *actions, const double *e_cmd, float *reward, uint8_t *active,
@@ -206,8 +209,7 @@ int n2n_env_tick(const n2n_config *cfg, const n2n_state *st, const int32_t *acti
     if (!cfg || !st || !actions || !e_cmd || !reward || !active || !done) return N2N_ERR_NULL;
     n2n_obs_out o0;
     memset(&o0, 0, sizeof o0);
-    hipLaunchKernelGGL(k_n2n<true>, dim3(st->N), dim3(WAVE), 0, (hipStream_t)stream, *cfg, *st, actions, e_cmd, reward, active, done, out ? *out : o0);
-    return (int)hipGetLastError();
+    return launch_n2n<true>(cfg, st, actions, e_cmd, reward, active, done, out ? *out : o0, (hipStream_t)stream);
 }
 
 void *n2n_resetter_create(const n2n_config *cfg, int32_t N, const uint32_t *seeds) {

@@ -203,3 +203,27 @@ def build_actor_critic(cfg, device):
     actor = SharedActor(enc, cfg.algo.embedding_dim, cfg.env.action_dim, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
     critic = SharedCritic(enc, cfg.algo.embedding_dim, 1, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
     return actor.to(device), critic.to(device)
+
+
+class GnnExtractor(nn.Module):
+    """The older one-hop encoder variant (reference obstacle_differ_3hop/mappo_parallel.py:34-70): per-pair
+    features through a two-layer MLP, mean over the L1-normalised adjacency, concatenated with the aggregated previous
+    communication embeddings and squeezed by a bottleneck layer.  Same parameter names (`one_hop.{0,2}`, `bottleneck.0`) and
+    initialisation stream as the reference, so its checkpoints load.  Its environment is not in the reference: block-level
+    parity only (tests/test_gnn_extractor.py against tests/golden/gnn_extractor.npz).
+      obs (*, A, K, F), last_comm_embedding (*, A, 2 O), adj (*, A, K) -> (*, A, O)"""
+
+    def __init__(self, input_size, middle_size, output_size, n_hops: int = 1, is_sn: bool = False):
+        super().__init__()
+        self.n_hop = n_hops
+        lin = (lambda a, b: _ortho_linear(a, b)) if is_sn else (lambda a, b: nn.Linear(a, b))
+        self.one_hop = nn.Sequential(lin(input_size, middle_size), nn.ReLU(), lin(middle_size, output_size), nn.ReLU())
+        self.bottleneck = nn.Sequential(lin(output_size + 2 * output_size, output_size), nn.ReLU())
+
+    def forward(self, obs, last_comm_embedding=None, adj=None):
+        A = adj.shape[-2]
+        abar = F.normalize(adj, p=1, dim=-1)
+        h0 = self.one_hop(obs)                                               # (*, A, K, O)
+        h0_agg = torch.matmul(abar.unsqueeze(-2), h0).squeeze(-2)            # (*, A, O)
+        comm_agg = torch.matmul(abar[..., :A], last_comm_embedding)          # the first A neighbours are the agents (:62-65)
+        return self.bottleneck(torch.cat([h0_agg, comm_agg], dim=-1))

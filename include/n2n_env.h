@@ -5,7 +5,7 @@
  * environment/env_n2n/particle_env.py:105 `ParticleEnv` cited per entry point.  The evader's heading command -- in the
  * reference the result of eva.e_f (scipy SLSQP, eva.py:36-53) -- is an INPUT here.  Conventions as in pe_env.h:
  * device pointers owned by the caller, caller's hipStream_t as void*, 0 == success.
- * One 64-lane wavefront steps one environment (lane = pursuer).
+ * Several environments share one 64-lane wavefront (lane = (environment, agent slot); 4 environments per wave at P = 16).
  */
 #ifndef N2N_ENV_H
 #define N2N_ENV_H
