@@ -248,6 +248,143 @@ __global__ void k_msg_agg_bwd_reduce(int nblk, int E, int din, const float *part
     }
 }
 
+// ---- all-ones adjacency over a STATIC neighbour set (the critic's obstacle relation in training) -------------------
+// With adj = ones the aggregate of a relation is  out_i[f] = (1/K) sum_j relu(c_i[f] - d_j[f]),  c_i = b + W p_i,  d_j = W q_j.
+// The obstacles q_j are per EPISODE (q_div = T rows share them), so for one (episode, feature) the K values d_j are fixed
+// for all T x P pursuer rows:  sum_j relu(c - d_j) = m c - S[m]  with m = #{j : d_j < c} and S the prefix sums of the sorted
+// d -- a piecewise-linear function of c.  One workgroup per (episode, 16 features): sorts d once (bitonic, LDS), builds the
+// prefix tables of d and of q (sorted order), then evaluates every (step, pursuer) by an 8-step binary search: O(log K)
+// instead of O(K) per pair.  Backward: dL/dc = g m, so db = sum g m, dW[:, k] = sum g (m p_i[k] - Q_k[m]) with Q_k the
+// prefix sums of q_j[k] in sorted order; m and the Q tables are saved by the forward pass.
+constexpr int SO_FC = 16, SO_TPB = 256, SO_PL = SO_TPB / SO_FC, SO_MAXK = 255, SO_LD = 257;  // 16 features x 16 pair lanes
+
+struct SortedArgs {
+    int R, P, K, E, q_div;
+    const float *p, *q, *W, *b;
+    int64_t p_rs, q_rs, o_is;
+};
+
+__host__ __device__ inline size_t so_fwd_lds(int K) { return sizeof(float) * ((size_t)SO_FC * SO_LD + (size_t)SO_FC * (K + 2) + SO_FC * SO_PL * 5 + 4 * (K + 1)) + SO_FC * 256; }
+__host__ __device__ inline size_t so_bwd_lds(int K) { return sizeof(float) * ((size_t)SO_FC * 4 * (K + 2) + SO_PL * SO_FC * 5); }
+
+__global__ __launch_bounds__(SO_TPB) void k_msg_ones_sorted_fwd(SortedArgs a, float *out, uint8_t *save_m, float *qtab) {
+    extern __shared__ __attribute__((aligned(16))) float so_smem[];
+    const int K = a.K, P = a.P, KP = K + 2;
+    float4 *s_q = (float4 *)so_smem;                                   // [K + 1]
+    float (*s_key)[SO_LD] = (float (*)[SO_LD])(so_smem + 4 * (K + 1));  // [FC][257] d sorted ascending (+inf padding)
+    float *s_pre = so_smem + 4 * (K + 1) + SO_FC * SO_LD;               // [FC][K + 2] prefix sums of the sorted d
+    float *s_chunk = s_pre + SO_FC * KP;                                // [FC][PL][5]
+    uint8_t (*s_idx)[256] = (uint8_t (*)[256])(s_chunk + SO_FC * SO_PL * 5);
+    const int tid = threadIdx.x, f = tid & (SO_FC - 1), pl = tid >> 4;
+    const int n = blockIdx.x, f0 = blockIdx.y * SO_FC;
+    const float *wrow = a.W + (size_t)(f0 + f) * 4;
+    const float w[4] = {wrow[0], wrow[1], wrow[2], wrow[3]};
+    const float bias = a.b[f0 + f];
+    for (int j = tid; j < K; j += SO_TPB) s_q[j] = ((const float4 *)(a.q + (size_t)n * a.q_rs))[j];
+    __syncthreads();
+    for (int j = pl; j < 256; j += SO_PL) {
+        s_key[f][j] = j < K ? msg_dot4(w, s_q[j]) : __builtin_inff();
+        s_idx[f][j] = (uint8_t)j;
+    }
+    __syncthreads();
+    for (int k = 2; k <= 256; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int e = pl; e < 128; e += SO_PL) {
+                const int i = ((e & ~(jj - 1)) << 1) | (e & (jj - 1)), ixj = i | jj;
+                const float x = s_key[f][i], y = s_key[f][ixj];
+                if ((x > y) == ((i & k) == 0)) {
+                    s_key[f][i] = y; s_key[f][ixj] = x;
+                    const uint8_t t = s_idx[f][i]; s_idx[f][i] = s_idx[f][ixj]; s_idx[f][ixj] = t;
+                }
+            }
+            __syncthreads();
+        }
+    // prefix tables: 16 lanes per feature, each sums a contiguous chunk, then offsets by the chunks before it; the prefix
+    // sums of d stay in LDS, those of q_j[0..3] (sorted order) go to qtab for the backward pass: [n][E][4][K + 1]
+    const int ch = (K + SO_PL - 1) / SO_PL, m0 = pl * ch, m1 = (m0 + ch < K) ? m0 + ch : K;
+    {
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int m = m0; m < m1; m++) {
+            const float4 qv = s_q[s_idx[f][m]];
+            acc[0] += s_key[f][m]; acc[1] += qv.x; acc[2] += qv.y; acc[3] += qv.z; acc[4] += qv.w;
+        }
+        for (int k = 0; k < 5; k++) s_chunk[(f * SO_PL + pl) * 5 + k] = acc[k];
+    }
+    __syncthreads();
+    {
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < pl; c++)
+            for (int k = 0; k < 5; k++) acc[k] += s_chunk[(f * SO_PL + c) * 5 + k];
+        float *qt = qtab ? qtab + ((size_t)n * a.E + f0 + f) * 4 * (K + 1) : nullptr;
+        if (pl == 0) {
+            s_pre[f * KP] = 0.f;
+            if (qt) for (int k = 0; k < 4; k++) qt[k * (K + 1)] = 0.f;
+        }
+        for (int m = m0; m < m1; m++) {
+            const float4 qv = s_q[s_idx[f][m]];
+            acc[0] += s_key[f][m]; acc[1] += qv.x; acc[2] += qv.y; acc[3] += qv.z; acc[4] += qv.w;
+            s_pre[f * KP + m + 1] = acc[0];
+            if (qt) { qt[m + 1] = acc[1]; qt[(K + 1) + m + 1] = acc[2]; qt[2 * (K + 1) + m + 1] = acc[3]; qt[3 * (K + 1) + m + 1] = acc[4]; }
+        }
+    }
+    __syncthreads();
+    const float invK = 1.f / (float)K;
+    const int pairs = a.q_div * P;
+    for (int pi = pl; pi < pairs; pi += SO_PL) {
+        const int t = pi / P, i = pi - t * P;
+        const size_t row = (size_t)n * a.q_div + t;
+        const float4 pv = *(const float4 *)(a.p + row * a.p_rs + i * 4);
+        const float c = bias + w[0] * pv.x + w[1] * pv.y + w[2] * pv.z + w[3] * pv.w;
+        int m = 0;
+#pragma unroll
+        for (int step = 128; step > 0; step >>= 1)
+            if (m + step <= K && s_key[f][m + step - 1] < c) m += step;   // m = #{j : d_j < c}
+        out[(row * P + i) * a.o_is + f0 + f] = ((float)m * c - s_pre[f * KP + m]) * invK;
+        if (save_m) save_m[(row * P + i) * a.E + f0 + f] = (uint8_t)m;
+    }
+}
+
+// partials: [gridDim.x = episodes][5][E] in the layout k_msg_agg_bwd_reduce sums (din = 4)
+__global__ __launch_bounds__(SO_TPB) void k_msg_ones_sorted_bwd(SortedArgs a, const float *gout, const uint8_t *save_m, const float *qtab,
+                                                               float *partials) {
+    extern __shared__ __attribute__((aligned(16))) float so_smem[];
+    const int tid = threadIdx.x, f = tid & (SO_FC - 1), pl = tid >> 4;
+    const int n = blockIdx.x, f0 = blockIdx.y * SO_FC, K = a.K, P = a.P, KQ = 4 * (K + 1);
+    float *s_qtab = so_smem;                       // [FC][4][K + 1], the layout of qtab
+    float *s_red = so_smem + SO_FC * 4 * (K + 2);   // [PL][FC][5]
+    {
+        const float *src = qtab + ((size_t)n * a.E + f0) * KQ;
+        for (int idx = tid; idx < SO_FC * KQ; idx += SO_TPB) s_qtab[idx] = src[idx];
+    }
+    __syncthreads();
+    const float *s_qt = s_qtab + f * KQ;
+    const float invK = 1.f / (float)K;
+    float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb = 0.f;
+    const int pairs = a.q_div * P;
+    for (int pi = pl; pi < pairs; pi += SO_PL) {
+        const int t = pi / P, i = pi - t * P;
+        const size_t row = (size_t)n * a.q_div + t;
+        const float4 pv = *(const float4 *)(a.p + row * a.p_rs + i * 4);
+        const float g = gout[(row * P + i) * a.o_is + f0 + f] * invK;
+        const int m = save_m[(row * P + i) * a.E + f0 + f];
+        const float gm = g * (float)m;
+        gb += gm;
+        gw[0] += gm * pv.x - g * s_qt[m];
+        gw[1] += gm * pv.y - g * s_qt[(K + 1) + m];
+        gw[2] += gm * pv.z - g * s_qt[2 * (K + 1) + m];
+        gw[3] += gm * pv.w - g * s_qt[3 * (K + 1) + m];
+    }
+    for (int k = 0; k < 4; k++) s_red[(pl * SO_FC + f) * 5 + k] = gw[k];
+    s_red[(pl * SO_FC + f) * 5 + 4] = gb;
+    __syncthreads();
+    if (tid < SO_FC * 5) {
+        const int ff = tid / 5, k = tid - ff * 5;
+        float sum = 0.f;
+        for (int c = 0; c < SO_PL; c++) sum += s_red[(c * SO_FC + ff) * 5 + k];   // fixed order: deterministic
+        partials[((size_t)n * 5 + k) * a.E + f0 + ff] = sum;
+    }
+}
+
 // ---- GAE ---------------------------------------------------------------------------------------------------
 __global__ void k_gae_scan(int N, int T, int P, const float *r, const float *v, const float *active, float gamma, float lamda,
                            float *adv, float *v_target, double *stats) {
@@ -1002,6 +1139,49 @@ int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
     const int tot = (din + 1) * E;
     hipLaunchKernelGGL(k_msg_agg_bwd_reduce, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, grid, E, din,
                        (const float *)workspace, dW, db);
+    return (int)hipGetLastError();
+}
+
+int dhgn_msg_agg_ones_sorted_ok(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, int32_t q_div) {
+    return R > 0 && P >= 1 && K >= 2 && K <= SO_MAXK && E >= SO_FC && (E % SO_FC) == 0 && din == 4 && q_div >= 1 && (R % q_div) == 0;
+}
+
+int64_t dhgn_msg_agg_ones_sorted_workspace(int32_t R, int32_t P, int32_t K, int32_t E, int32_t q_div, int64_t *m_bytes, int64_t *qtab_bytes,
+                                           int64_t *partial_bytes) {
+    const int64_t mb = (int64_t)R * P * E, qb = (int64_t)(R / q_div) * E * 4 * (K + 1) * sizeof(float), pb = (int64_t)(R / q_div) * 5 * E * sizeof(float);
+    if (m_bytes) *m_bytes = mb;
+    if (qtab_bytes) *qtab_bytes = qb;
+    if (partial_bytes) *partial_bytes = pb;
+    return mb + qb + pb;
+}
+
+int dhgn_msg_agg_ones_sorted_fwd(int32_t R, int32_t P, int32_t K, int32_t E, const float *p, int64_t p_rs, const float *q, int64_t q_rs,
+                                 int32_t q_div, const float *W, const float *b, float *out, int64_t out_stride, uint8_t *save_m, float *qtab,
+                                 void *stream) {
+    if (!dhgn_msg_agg_ones_sorted_ok(R, P, K, E, 4, q_div) || !p || !q || !W || !b || !out) return MO_ERR_BAD_ARG;
+    if ((q_rs & 3) || (p_rs & 3) || out_stride < E || ((uintptr_t)p & 15) || ((uintptr_t)q & 15)) return MO_ERR_BAD_ARG;
+    SortedArgs a{R, P, K, E, q_div, p, q, W, b, p_rs, q_rs, out_stride};
+    if (so_fwd_lds(K) > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_msg_ones_sorted_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)so_fwd_lds(K));
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_msg_ones_sorted_fwd, dim3(R / q_div, E / SO_FC), dim3(SO_TPB), so_fwd_lds(K), (hipStream_t)stream, a, out, save_m, qtab);
+    return (int)hipGetLastError();
+}
+
+int dhgn_msg_agg_ones_sorted_bwd(int32_t R, int32_t P, int32_t K, int32_t E, const float *p, int64_t p_rs, int32_t q_div, const float *gout,
+                                 int64_t gout_stride, const uint8_t *save_m, const float *qtab, float *dW, float *db, void *partials,
+                                 void *stream) {
+    if (!dhgn_msg_agg_ones_sorted_ok(R, P, K, E, 4, q_div) || !p || !gout || !save_m || !qtab || !dW || !db || !partials) return MO_ERR_BAD_ARG;
+    if ((p_rs & 3) || gout_stride < E || ((uintptr_t)p & 15)) return MO_ERR_BAD_ARG;
+    SortedArgs a{R, P, K, E, q_div, p, nullptr, nullptr, nullptr, p_rs, 0, gout_stride};
+    const int nblk = R / q_div;
+    if (so_bwd_lds(K) > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_msg_ones_sorted_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)so_bwd_lds(K));
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_msg_ones_sorted_bwd, dim3(nblk, E / SO_FC), dim3(SO_TPB), so_bwd_lds(K), (hipStream_t)stream, a, gout, save_m, qtab, (float *)partials);
+    hipLaunchKernelGGL(k_msg_agg_bwd_reduce, dim3((5 * E + 3) / 4), dim3(256), 0, (hipStream_t)stream, nblk, (int)E, 4, (const float *)partials, dW, db);
     return (int)hipGetLastError();
 }
 

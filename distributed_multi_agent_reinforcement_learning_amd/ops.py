@@ -12,7 +12,8 @@ import torch.nn.functional as F
 from . import build as _build
 
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
-EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "gae_advnorm", "categorical_sample",
+EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
+           "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
            "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
@@ -37,6 +38,11 @@ def load_library():
         L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
         L.dhgn_msg_agg_bwd_workspace.restype = i64
+        L.dhgn_msg_agg_ones_sorted_ok.argtypes = [i32] * 6
+        L.dhgn_msg_agg_ones_sorted_workspace.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp]
+        L.dhgn_msg_agg_ones_sorted_workspace.restype = i64
+        L.dhgn_msg_agg_ones_sorted_fwd.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, vp, vp, i64, vp, vp, vp]
+        L.dhgn_msg_agg_ones_sorted_bwd.argtypes = [i32, i32, i32, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, vp]
         L.gae_advnorm.argtypes = [i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
         L.categorical_sample.argtypes = [i32, i32, vp, C.c_uint64, C.c_uint64, i32, vp, vp, vp]
         L.categorical_sample_counter.argtypes = [i32, i32, vp, C.c_uint64, vp, i32, vp, vp, vp]
@@ -180,6 +186,15 @@ def msg_agg(p, q, e, adj, W, b, adj_mode=ADJ_TENSOR, kvalid=None, q_div=1):
                          adj_mode, q_div)
 
 
+SORTED_ONES_MIN_QDIV = 8  # rows sharing one neighbour set from which the sort + binary-search kernels beat the O(K) loop
+
+
+def _sorted_ones_ok(L, p, q, W, adj_mode, q_div):
+    """the critic's all-ones obstacle relation over a neighbour set shared by q_div rows: O(log K) kernels (mappo_ops.h)"""
+    return (adj_mode == ADJ_ONES and q_div >= SORTED_ONES_MIN_QDIV and p.stride(0) % 4 == 0 and p.data_ptr() % 16 == 0 and q.data_ptr() % 16 == 0
+            and bool(L.dhgn_msg_agg_ones_sorted_ok(p.shape[0], p.shape[1], q.shape[1], W.shape[0], W.shape[1], q_div)))
+
+
 class _MsgAgg3(torch.autograd.Function):
     """The three relations of DHGN.encoder in one autograd node writing one (R, P, 3, E) tensor (relation r in slot r), so
     the shared AGG_vertex_0 layer runs as a single GEMM on a view and no stack / concatenate copies exist."""
@@ -196,17 +211,27 @@ class _MsgAgg3(torch.autograd.Function):
         slot = lambda r: C.c_void_p(out.data_ptr() + 4 * r * E)
         _msg_call("fwd", L, p, p, e2, adj_p, None, ws[0], ws[1], mode, 1, slot(0), 3 * E)
         _msg_call("fwd", L, p, e, None, adj_e, None, ws[2], ws[3], mode, 1, slot(1), 3 * E)
-        _msg_call("fwd", L, p, o, None, adj_o, kvalid, ws[4], ws[5], mode_o, q_div, slot(2), 3 * E)
-        ctx.save_for_backward(p, e, o, adj_p, adj_e, adj_o, kvalid, *ws)
+        save_m = qtab = None
+        ctx.sorted_o = _sorted_ones_ok(L, p, o, ws[4], mode_o, q_div)
+        if ctx.sorted_o:
+            K = o.shape[1]
+            if any(ctx.needs_input_grad):
+                save_m = torch.empty((R, P, E), dtype=torch.uint8, device=p.device)
+                qtab = torch.empty((R // q_div, E, 4, K + 1), dtype=torch.float32, device=p.device)
+            _check(L.dhgn_msg_agg_ones_sorted_fwd(R, P, K, E, _ptr(p), p.stride(0), _ptr(o), o.stride(0), q_div, _ptr(ws[4]), _ptr(ws[5]), slot(2), 3 * E,
+                                                  _ptr(save_m), _ptr(qtab), _stream()), "dhgn_msg_agg_ones_sorted_fwd")
+        else:
+            _msg_call("fwd", L, p, o, None, adj_o, kvalid, ws[4], ws[5], mode_o, q_div, slot(2), 3 * E)
+        ctx.save_for_backward(p, e, o, adj_p, adj_e, adj_o, kvalid, save_m, qtab, *ws)
         ctx.meta = (mode, mode_o, q_div)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         L = load_library()
-        p, e, o, adj_p, adj_e, adj_o, kvalid, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
+        p, e, o, adj_p, adj_e, adj_o, kvalid, save_m, qtab, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
         mode, mode_o, q_div = ctx.meta
-        R = p.shape[0]
+        R, P = p.shape[0], p.shape[1]
         E = W0.shape[0]
         gout = gout.contiguous()
         slot = lambda r: C.c_void_p(gout.data_ptr() + 4 * r * E)
@@ -214,6 +239,12 @@ class _MsgAgg3(torch.autograd.Function):
         for r, (q, ee, adj, kv, W, b, m, qd) in enumerate(((p, e.reshape(R, 4), adj_p, None, W0, b0, mode, 1), (e, None, adj_e, None, W1, b1, mode, 1),
                                                            (o, None, adj_o, kvalid, W2, b2, mode_o, q_div))):
             dW, db = torch.empty_like(W), torch.empty_like(b)
+            if r == 2 and ctx.sorted_o:
+                part = torch.empty((R // q_div) * 5 * E, dtype=torch.float32, device=p.device)
+                _check(L.dhgn_msg_agg_ones_sorted_bwd(R, P, o.shape[1], E, _ptr(p), p.stride(0), q_div, slot(2), 3 * E, _ptr(save_m), _ptr(qtab),
+                                                      _ptr(dW), _ptr(db), _ptr(part), _stream()), "dhgn_msg_agg_ones_sorted_bwd")
+                grads += [dW, db]
+                continue
             ws = _workspace(p.device, E, W.shape[1])
             _msg_call("bwd", L, p, q, ee, adj, kv, W, b, m, qd, slot(r), 3 * E, (_ptr(dW), _ptr(db), _ptr(ws)))
             grads += [dW, db]

@@ -55,6 +55,26 @@ int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
                      const float *gout, int64_t gout_stride, float *dW, float *db, void *workspace, void *stream);
 
 /*
+ * The same aggregate for adjacency == ones over a neighbour set shared by q_div consecutive rows (the critic's obstacle relation
+ * in training: torch.ones_like(adj) over the padded obstacle slots, AttributeDataset :64-65, q = the episode's obstacles) in
+ * O(log K) per (row, agent, feature) instead of O(K): per (q-row, feature) the K pre-activation offsets d_j = W q_j are sorted
+ * once, sum_j relu(c - d_j) = m c - prefix_d[m] with m = #{d_j < c} found by binary search (csrc/mappo_ops.hip
+ * k_msg_ones_sorted_*).  din == 4, K <= 255, E a multiple of 16, R a multiple of q_div (dhgn_msg_agg_ones_sorted_ok).
+ * fwd: save_m [R][P][E] u8 and qtab [R/q_div][E][4][K+1] f32 (may be NULL without a backward pass) are what bwd consumes;
+ * bwd: dW [E][4], db [E] OVERWRITTEN; partials: scratch of the size dhgn_msg_agg_ones_sorted_workspace reports.
+ * Sums are reassociated (prefix sums): results agree with dhgn_msg_agg_fwd/bwd(MO_ADJ_ONES) to fp32 rounding, not bit for bit.
+ */
+int dhgn_msg_agg_ones_sorted_ok(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, int32_t q_div);
+int64_t dhgn_msg_agg_ones_sorted_workspace(int32_t R, int32_t P, int32_t K, int32_t E, int32_t q_div, int64_t *m_bytes, int64_t *qtab_bytes,
+                                           int64_t *partial_bytes);
+int dhgn_msg_agg_ones_sorted_fwd(int32_t R, int32_t P, int32_t K, int32_t E, const float *p, int64_t p_row_stride, const float *q,
+                                 int64_t q_row_stride, int32_t q_div, const float *W, const float *b, float *out, int64_t out_stride,
+                                 uint8_t *save_m, float *qtab, void *stream);
+int dhgn_msg_agg_ones_sorted_bwd(int32_t R, int32_t P, int32_t K, int32_t E, const float *p, int64_t p_row_stride, int32_t q_div,
+                                 const float *gout, int64_t gout_stride, const uint8_t *save_m, const float *qtab, float *dW, float *db,
+                                 void *partials, void *stream);
+
+/*
  * GAE reverse scan + value target + advantage normalisation (DHGN/mappo_parallel.py:643-658):
  *   delta = (r + gamma v[:,1:] - v[:,:-1]) * active ; gae_t = delta_t + gamma lamda gae_{t+1}
  *   v_target = adv + v[:,:-1] ; if use_adv_norm: adv = (adv - mean) / (std_unbiased + 1e-5) * active

@@ -354,3 +354,45 @@ def test_msg_agg_bit_packed_adjacency_equals_float_adjacency(K, P):
     args = lambda ao: (p, e, o, adj_p, adj_e, ao, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2], False, None, T)
     with torch.no_grad():
         assert torch.equal(ops.msg_agg3(*args(adj)), ops.msg_agg3(*args(bits)))
+
+
+@pytest.mark.parametrize("P,K,T", [(8, 176, 150), (4, 176, 16), (15, 97, 12), (8, 2, 9)])
+def test_sorted_all_ones_relation_matches_dense_kernels(P, K, T):
+    """The critic's all-ones obstacle relation in training (DHGN/mappo_parallel.py:64-65, 323-348): the sort +
+    prefix-sum + binary-search kernels (O(log K) per pair) against the O(K) kernels and against the materialised fp64 reference:
+    forward within 2e-5, dW / db within 2e-4 of the gradient scale (prefix sums reassociate the fp32 additions)."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(P * K + T)
+    N, E = 7, 128
+    R = N * T
+    p = (torch.randn(R, P, 4) * 10 + 20).cuda()
+    e = (torch.randn(R, 1, 4) * 10 + 20).cuda()
+    o = torch.zeros(N, K, 4)
+    kv = torch.randint(1, K + 1, (N,))
+    for n in range(N):      # real obstacles [x, y, 0, 0], zero-padded slots: many equal d values (ties)
+        o[n, :kv[n], :2] = torch.randint(0, 40, (int(kv[n]), 2)).float()
+    o = o.cuda()
+    adj_p = torch.ones(R, P, P).cuda(); adj_e = torch.ones(R, P, 1).cuda(); adj_o = torch.ones(R, P, K).cuda()
+    g = torch.randn(R, P, 3, E, generator=torch.Generator().manual_seed(5)).cuda()
+    res = {}
+    for name, thr in (("sorted", 1), ("dense", 10 ** 9)):
+        ops.SORTED_ONES_MIN_QDIV = thr
+        Ws = [(torch.randn(E, d, generator=torch.Generator().manual_seed(10 + d)) * 0.3).cuda().requires_grad_(True) for d in (8, 4, 4)]
+        bs = [(torch.randn(E, generator=torch.Generator().manual_seed(20 + k)) * 0.1).cuda().requires_grad_(True) for k in range(3)]
+        out = ops.msg_agg3(p, e, o, adj_p, adj_e, adj_o, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2], True, None, T)
+        out.backward(g)
+        res[name] = (out.detach(), Ws[2].grad.clone(), bs[2].grad.clone(), Ws[0].grad.clone())
+    ops.SORTED_ONES_MIN_QDIV = 8
+    so, de = res["sorted"], res["dense"]
+    assert torch.equal(so[0][:, :, :2], de[0][:, :, :2]) and torch.equal(so[3], de[3])          # the other relations are untouched
+    assert torch.allclose(so[0][:, :, 2], de[0][:, :, 2], rtol=2e-5, atol=2e-5)
+    # fp64 reference of relation 2
+    W64, b64 = res["dense"][1].new_tensor(0), None
+    Wr = (torch.randn(E, 4, generator=torch.Generator().manual_seed(14)) * 0.3).double().requires_grad_(True)
+    br = (torch.randn(E, generator=torch.Generator().manual_seed(22)) * 0.1).double().requires_grad_(True)
+    rel = p.cpu().double().reshape(N, T, P, 1, 4) - o.cpu().double().reshape(N, 1, 1, K, 4)
+    ref = torch.relu(torch.nn.functional.linear(rel, Wr, br)).mean(-2).reshape(R, P, E)
+    ref.backward(g[:, :, 2].cpu().double())
+    assert torch.allclose(so[0][:, :, 2].cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
+    for mine, want in ((so[1], Wr.grad), (so[2], br.grad)):
+        assert (mine.cpu().double() - want).abs().max() <= 2e-4 * want.abs().max(), ((mine.cpu().double() - want).abs().max(), want.abs().max())

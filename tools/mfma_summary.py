@@ -1,0 +1,37 @@
+"""rocprofv3 outputs of tools/profile_gru.py -> profiles/r02_gru_mfma_counters.json: per hand-written MFMA kernel the average
+duration (kernel trace), MFMA busy cycles, and MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE x #SIMDs) -- the
+derived-counter formula rocprofv3 lists for MfmaUtil -- next to the algorithmic fp32 rate against the 157.3 TFLOP/s peak.
+  python tools/mfma_summary.py <dir>"""
+import csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = sys.argv[1]
+KERNELS = {"k_gru_seq_fwd": 2.0 * 150 * 3280 * 128 * 384, "k_gru_seq_bwd": 2.0 * 150 * 3280 * 384 * 128, "k_gru_cell": 2.0 * 32768 * 128 * 768,
+           "k_wgrad<3, 1>": 2.0 * 492000 * 384 * 128}
+cnt = {}
+for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        for k in KERNELS:
+            if k in r["Kernel_Name"]:
+                a = cnt.setdefault(k, {}).setdefault(r["Counter_Name"], [0, 0.0])
+                a[0] += 1; a[1] += float(r["Counter_Value"])
+dur = {}
+for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        for k in KERNELS:
+            if k in r["Name"]:
+                dur[k] = float(r["AverageNs"]) * 1e-9
+out = {"method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES (one pass) and "
+                 "--kernel-trace --stats (second pass) of tools/profile_gru.py; MfmaUtil = MFMA busy cycles / (GRBM_GUI_ACTIVE * 1024 SIMDs), "
+                 "GRBM_GUI_ACTIVE as reported (summed over the 8 XCDs -> divided by 8)", "kernels": {}}
+for k, fl in KERNELS.items():
+    c = {n: v[1] / v[0] for n, v in cnt.get(k, {}).items()}
+    e = {"counters_avg_per_launch": {n: round(v, 1) for n, v in c.items()}}
+    if k in dur:
+        e["avg_duration_us"] = round(dur[k] * 1e6, 1)
+        e["algorithmic_TFLOPs"] = round(fl / dur[k] / 1e12, 2)
+        e["frac_of_157.3_TFLOPs"] = round(fl / dur[k] / 157.3e12, 4)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        e["MfmaUtil_percent"] = round(100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 2)
+    out["kernels"][k] = e
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02_gru_mfma_counters.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

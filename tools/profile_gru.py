@@ -1,0 +1,30 @@
+"""Runs the hand-written fp32-MFMA kernels of the update / rollout at the benchmark's shapes (cfg2: mini-batch 410 episodes,
+T = 150, P = 8 -> B = 3280 sequence rows; rollout B = 32768 rows) -- the target of the rocprofv3 passes whose MFMA-utilisation
+counters are committed under profiles/ (north star: "rocprof-reported MFMA utilisation for the GRU GEMMs"):
+  rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/profile_gru.py
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES --output-format csv -- python3 tools/profile_gru.py
+Summarise with tools/mfma_summary.py."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from types import SimpleNamespace
+from distributed_multi_agent_reinforcement_learning_amd import ops
+
+dev = "cuda"
+T, B, Br, Kr = 150, 3280, 32768, 492000
+torch.manual_seed(0)
+w = lambda *s: torch.randn(*s, device=dev) * 0.08
+gm = SimpleNamespace(num_layers=1, weight_ih_l0=w(384, 128), weight_hh_l0=w(384, 128), bias_ih_l0=torch.zeros(384, device=dev), bias_hh_l0=torch.zeros(384, device=dev))
+for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+    getattr(gm, k).requires_grad_(True)
+x = torch.randn(T, B, 128, device=dev, requires_grad=True)
+h0 = torch.zeros(1, B, 128, device=dev)
+for rep in range(4):   # k_gru_seq_fwd + k_gru_seq_bwd + k_wgrad (the sequence mode of the update)
+    out, _ = ops.gru(x, h0, gm)
+    out.backward(torch.randn_like(out))
+xr, hr = torch.randn(1, Br, 128, device=dev), torch.randn(1, Br, 128, device=dev)
+with torch.no_grad():
+    for rep in range(20):  # k_gru_cell (one rollout step)
+        ops.gru(xr, hr, gm)
+torch.cuda.synchronize()
+print("done")
