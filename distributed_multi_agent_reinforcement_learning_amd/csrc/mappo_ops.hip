@@ -108,8 +108,7 @@ __device__ __forceinline__ MsgLds msg_lds(float *smem, int P, int K) {
 // accumulator per agent in registers (PT = P rounded up to 4, 8 or 16).  Neighbour columns no agent sees are skipped
 // (wave-uniform), which removes ~60 % of the obstacle columns of LiDAR adjacency rows.
 template <int PT>
-__global__ void k_msg_agg_fwd(MsgArgs a, float *out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void msg_agg_fwd_rows(const MsgArgs &a, float *out, float *smem) {
     const int P = a.P, K = a.K, E = a.E;
     const MsgLds l = msg_lds(smem, P, K);
     const int tid = threadIdx.x, f = tid;  // lane == feature
@@ -156,6 +155,23 @@ __global__ void k_msg_agg_fwd(MsgArgs a, float *out) {
             if (i < P) out[((size_t)r * P + i) * a.o_is + f] = acc[i] * l.inv[i];
         __syncthreads();
     }
+}
+
+template <int PT>
+__global__ void k_msg_agg_fwd(MsgArgs a, float *out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    msg_agg_fwd_rows<PT>(a, out, smem);
+}
+
+// The three relations of DHGN.encoder (defender, evader, obstacle; DHGN/mappo_parallel.py:256-281) in ONE launch: every
+// workgroup walks its rows three times, once per relation.  The rollout's per-tick calls handle 4096 rows each, ~15-60 us of
+// mostly launch ramp and staging latency per kernel; one launch instead of three keeps the workgroups resident.
+template <int PT>
+__global__ void k_msg_agg3_fwd(MsgArgs a0, MsgArgs a1, MsgArgs a2, float *out0, float *out1, float *out2) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    msg_agg_fwd_rows<PT>(a0, out0, smem);
+    msg_agg_fwd_rows<PT>(a1, out1, smem);
+    msg_agg_fwd_rows<PT>(a2, out2, smem);
 }
 
 // partials: [gridDim.x][din + 1][E].  dW[:, k<4] = sum_i G_i p_i[k] - sum_j H_j q_j[k] with G_i = sum_j g_ij, H_j = sum_i g_ij,
@@ -1118,6 +1134,28 @@ int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
     if (P <= 4) hipLaunchKernelGGL(k_msg_agg_fwd<4>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
     else if (P <= 8) hipLaunchKernelGGL(k_msg_agg_fwd<8>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
     else hipLaunchKernelGGL(k_msg_agg_fwd<16>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
+    return (int)hipGetLastError();
+}
+
+int dhgn_msg_agg3_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_rs, float *out, int64_t out_stride,
+                      void *stream) {
+    if (!rel || !p || !out || R < 0) return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    MsgArgs a[3];
+    size_t lds = 0;
+    for (int r = 0; r < 3; r++) {
+        const mo_msg_rel &m = rel[r];
+        int rc = check_msg(R, P, m.K, E, m.din, m.q_div, m.adj_mode, m.adj, m.kvalid, m.e);
+        if (rc) return rc;
+        if ((m.q_rs & 3) || out_stride < 3 * E) return MO_ERR_BAD_ARG;
+        a[r] = MsgArgs{R, P, m.K, E, m.din, m.q_div, m.adj_mode, p, m.q, m.e, (const float *)m.adj, p_rs, m.q_rs, m.e_rs, m.adj_rs, out_stride, m.kvalid, m.W, m.b};
+        const size_t l = msg_lds_bytes(P, m.K);
+        lds = l > lds ? l : lds;
+    }
+    const int grid = R < 8192 ? R : 8192;
+    if (P <= 4) hipLaunchKernelGGL(k_msg_agg3_fwd<4>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], out, out + E, out + 2 * E);
+    else if (P <= 8) hipLaunchKernelGGL(k_msg_agg3_fwd<8>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], out, out + E, out + 2 * E);
+    else hipLaunchKernelGGL(k_msg_agg3_fwd<16>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], out, out + E, out + 2 * E);
     return (int)hipGetLastError();
 }
 

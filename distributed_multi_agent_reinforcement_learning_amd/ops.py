@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from . import build as _build
 
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
-EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
+EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
            "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
@@ -36,6 +36,7 @@ def load_library():
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
         L.dhgn_msg_agg_fwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp]
         L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
+        L.dhgn_msg_agg3_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, i64, vp]
         L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
         L.dhgn_msg_agg_bwd_workspace.restype = i64
         L.dhgn_msg_agg_ones_sorted_ok.argtypes = [i32] * 6
@@ -186,6 +187,38 @@ def msg_agg(p, q, e, adj, W, b, adj_mode=ADJ_TENSOR, kvalid=None, q_div=1):
                          adj_mode, q_div)
 
 
+class MsgRel(C.Structure):
+    """include/mappo_ops.h mo_msg_rel"""
+    _fields_ = [("K", C.c_int32), ("din", C.c_int32), ("q_div", C.c_int32), ("adj_mode", C.c_int32), ("q", C.c_void_p), ("q_rs", C.c_int64),
+                ("e", C.c_void_p), ("e_rs", C.c_int64), ("adj", C.c_void_p), ("adj_rs", C.c_int64), ("kvalid", C.c_void_p), ("W", C.c_void_p),
+                ("b", C.c_void_p)]
+
+
+def _msg3_call(L, p, rels, out, E):
+    """rels: three (q, e, adj, kvalid, W, b, adj_mode, q_div); one launch for the three relations"""
+    R, P = p.shape[0], p.shape[1]
+    arr = (MsgRel * 3)()
+    for r, (q, e, adj, kv, W, b, mode, qd) in enumerate(rels):
+        K, din = q.shape[1], W.shape[1]
+        assert _rows_ok(q) and q.shape[2] == 4 and q.shape[0] * qd == R and q.stride(0) % 4 == 0
+        m = arr[r]
+        m.K, m.din, m.q_div, m.adj_mode = K, din, qd, mode
+        m.q, m.q_rs = q.data_ptr(), q.stride(0)
+        if e is not None:
+            assert e.shape == (R, 4) and _rows_ok(e)
+            m.e, m.e_rs = e.data_ptr(), e.stride(0)
+        if mode in (ADJ_TENSOR, ADJ_BITS):
+            assert adj.shape == (R, P, K if mode == ADJ_TENSOR else adj_row_words(K)) and _rows_ok(adj)
+            assert adj.dtype == (torch.float32 if mode == ADJ_TENSOR else torch.int32)
+            m.adj, m.adj_rs = adj.data_ptr(), adj.stride(0)
+        if mode == ADJ_VALID:
+            assert kv.dtype == torch.int32 and kv.is_contiguous() and kv.shape[0] * qd == R
+            m.kvalid = kv.data_ptr()
+        m.W, m.b = W.data_ptr(), b.data_ptr()
+    assert p.dtype == torch.float32 and p.shape[2] == 4 and _rows_ok(p)
+    _check(L.dhgn_msg_agg3_fwd(C.cast(arr, C.c_void_p), R, P, E, _ptr(p), p.stride(0), _ptr(out), 3 * E, _stream()), "dhgn_msg_agg3_fwd")
+
+
 SORTED_ONES_MIN_QDIV = 8  # rows sharing one neighbour set from which the sort + binary-search kernels beat the O(K) loop
 
 
@@ -209,10 +242,16 @@ class _MsgAgg3(torch.autograd.Function):
         e2 = e.reshape(R, 4)
         out = torch.empty((R, P, 3, E), dtype=torch.float32, device=p.device)
         slot = lambda r: C.c_void_p(out.data_ptr() + 4 * r * E)
-        _msg_call("fwd", L, p, p, e2, adj_p, None, ws[0], ws[1], mode, 1, slot(0), 3 * E)
-        _msg_call("fwd", L, p, e, None, adj_e, None, ws[2], ws[3], mode, 1, slot(1), 3 * E)
         save_m = qtab = None
         ctx.sorted_o = _sorted_ones_ok(L, p, o, ws[4], mode_o, q_div)
+        if not ctx.sorted_o:   # the three relations in one launch
+            _msg3_call(L, p, ((p, e2, adj_p, None, ws[0], ws[1], mode, 1), (e, None, adj_e, None, ws[2], ws[3], mode, 1),
+                              (o, None, adj_o, kvalid, ws[4], ws[5], mode_o, q_div)), out, E)
+            ctx.save_for_backward(p, e, o, adj_p, adj_e, adj_o, kvalid, save_m, qtab, *ws)
+            ctx.meta = (mode, mode_o, q_div)
+            return out
+        _msg_call("fwd", L, p, p, e2, adj_p, None, ws[0], ws[1], mode, 1, slot(0), 3 * E)
+        _msg_call("fwd", L, p, e, None, adj_e, None, ws[2], ws[3], mode, 1, slot(1), 3 * E)
         if ctx.sorted_o:
             K = o.shape[1]
             if any(ctx.needs_input_grad):

@@ -43,6 +43,22 @@ int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
                      float *out, int64_t out_stride /* elements between consecutive (row, agent) vectors, >= E */, void *stream);
 
 /*
+ * The three relations of DHGN.encoder for the same R rows in ONE launch (DHGN/mappo_parallel.py:256-281): relation r writes
+ * slot r of out [R][P][3][E] (out_stride = elements between consecutive (row, agent) vectors, >= 3 E).  Same arithmetic as
+ * three dhgn_msg_agg_fwd calls (bit-identical); exists because the rollout's per-tick calls are launch-latency bound.
+ */
+typedef struct mo_msg_rel {
+    int32_t K, din, q_div, adj_mode;
+    const float *q; int64_t q_rs;       /* [R/q_div][K][4] */
+    const float *e; int64_t e_rs;       /* [R][4] or NULL (din == 4) */
+    const void *adj; int64_t adj_rs;    /* MO_ADJ_TENSOR: float [R][P][K]; MO_ADJ_BITS: packed words; else NULL */
+    const int32_t *kvalid;              /* MO_ADJ_VALID: [R/q_div] */
+    const float *W, *b;                 /* [E][din], [E] */
+} mo_msg_rel;
+int dhgn_msg_agg3_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_row_stride, float *out,
+                      int64_t out_stride, void *stream);
+
+/*
  * Backward of the above w.r.t. W and b (the inputs are data, they carry no gradient): recomputes the
  * pre-activation, masks with ReLU', reduces over all (r,i,j) without atomics (per-workgroup partials in
  * `workspace`, then one deterministic second pass).  gout [R][P][E]; dW [E][din]; db [E] are OVERWRITTEN.

@@ -396,3 +396,27 @@ def test_sorted_all_ones_relation_matches_dense_kernels(P, K, T):
     assert torch.allclose(so[0][:, :, 2].cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
     for mine, want in ((so[1], Wr.grad), (so[2], br.grad)):
         assert (mine.cpu().double() - want).abs().max() <= 2e-4 * want.abs().max(), ((mine.cpu().double() - want).abs().max(), want.abs().max())
+
+
+@pytest.mark.parametrize("critic", [False, True])
+def test_fused_three_relation_launch_equals_three_launches(critic):
+    """dhgn_msg_agg3_fwd (one launch for the defender / evader / obstacle relation of DHGN.encoder) against three
+    dhgn_msg_agg_fwd launches: bit-identical, actor adjacency (float and packed) and the critic's rollout form (ADJ_VALID)."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(3 + critic)
+    R, P, K, E = 300, 8, 176, 128
+    p = (torch.randn(R, P, 4) * 10 + 20).cuda(); e = (torch.randn(R, 1, 4) * 10 + 20).cuda()
+    o = torch.zeros(R, K, 4); o[:, :, :2] = torch.randint(0, 40, (R, K, 2)).float(); o = o.cuda()
+    kv = torch.randint(0, K + 1, (R,), dtype=torch.int32).cuda()
+    adj_p = (torch.rand(R, P, P) < 0.5).float().cuda(); adj_e = (torch.rand(R, P, 1) < 0.5).float().cuda()
+    adj_o = (torch.rand(R, P, K) < 0.1).float().cuda()
+    Ws = [(torch.randn(E, d) * 0.3).cuda() for d in (8, 4, 4)]; bs = [(torch.randn(E) * 0.1).cuda() for _ in range(3)]
+    with torch.no_grad():
+        for ao in ((adj_o, ops.pack_adj_bits(adj_o)) if not critic else (adj_o,)):
+            fused = ops.msg_agg3(p, e, o, adj_p, adj_e, ao, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2], critic, kv if critic else None, 1)
+            mode = ops.ADJ_ONES if critic else ops.ADJ_TENSOR
+            mode_o = ops.ADJ_VALID if critic else (ops.ADJ_BITS if ao.dtype == torch.int32 else ops.ADJ_TENSOR)
+            r0 = ops.msg_agg(p, p, e.reshape(R, 4), adj_p, Ws[0], bs[0], mode)
+            r1 = ops.msg_agg(p, e, None, adj_e, Ws[1], bs[1], mode)
+            r2 = ops.msg_agg(p, o, None, ao, Ws[2], bs[2], mode_o, kv)
+            assert torch.equal(fused, torch.stack((r0, r1, r2), 2))
