@@ -154,21 +154,24 @@ def measure_compute_kernels(trainer, cfg):
                              rows=Kr, hbm_GBps=round((384 + 128) * 4.0 * Kr / t / 1e9, 1))
         del ga, xa
         Br = trainer.num_envs * P
-        gm = SimpleNamespace(num_layers=1, weight_ih_l0=torch.randn(384, 128, device=dev) * 0.08, weight_hh_l0=torch.randn(384, 128, device=dev) * 0.08,
-                             bias_ih_l0=torch.zeros(384, device=dev), bias_hh_l0=torch.zeros(384, device=dev))
-        xr = torch.randn(1, Br, 128, device=dev); hr = torch.randn(1, Br, 128, device=dev)
-        with torch.no_grad():
-            t = timeit(lambda: ops.gru(xr, hr, gm), n=20)
+        xr, hr, ho = torch.randn(Br, 128, device=dev), torch.randn(Br, 128, device=dev), torch.empty(Br, 128, device=dev)
+        wi, wh, bi, bh = w, torch.randn(384, 128, device=dev) * 0.08, b, torch.zeros(384, device=dev)
+        t = timeit(lambda: L.gru_cell_fwd(Br, 128, ptr(xr), ptr(hr), ptr(wi), ptr(wh), ptr(bi), ptr(bh), ptr(ho), st), n=20)  # C ABI directly
         out["gru_cell"] = entry("k_gru_cell (one rollout GRU layer step: both projections + gates, one launch)", 2.0 * Br * 128 * 768, t, rows=Br)
     R = mb * T
-    p = torch.rand(R, P, 4, device=dev) * 40; q = torch.rand(mb, O, 4, device=dev) * 40
+    p = torch.rand(R, P, 4, device=dev) * 40; q = torch.zeros(mb, O, 4, device=dev); q[:, :, :2] = torch.randint(0, 40, (mb, O, 2), device=dev).float()
     W = torch.randn(E, 4, device=dev) * 0.3; bb = torch.zeros(E, device=dev)
+    fl_alg = R * P * O * (2 * 4 * E + 3 * E)
+    note = ("`achieved` prices the reference formulation W (p_i - q_j) + b -> relu -> mean (11 E flops per pair, SURVEY 8d): an "
+            "algorithmic-equivalent rate, not a hardware fraction; the kernel executes far fewer flops")
     with torch.no_grad():
         t = timeit(lambda: ops.msg_agg(p, q, None, None, W, bb, ops.ADJ_ONES, None, T))
-    fl_alg = R * P * O * (2 * 4 * E + 3 * E)
-    out["msg_agg_fwd"] = entry("dhgn_msg_agg_fwd, critic obstacle relation (all-ones adjacency over O slots)", fl_alg, t, bound="valu", rows=R,
-                               note="`achieved` prices the reference formulation W (p_i - q_j) + b -> relu -> mean (11 E flops per pair, "
-                                    "SURVEY 8d): an algorithmic-equivalent rate, not a hardware fraction; the kernel executes fewer flops")
+    out["msg_agg_fwd_dense"] = entry("dhgn_msg_agg_fwd(MO_ADJ_ONES): O(K) loop per pair (the rollout's critic relation uses this form over the real obstacles)",
+                                     fl_alg, t, bound="valu", rows=R, note=note)
+    oo = torch.empty(R, P, E, device=dev)
+    t = timeit(lambda: L.dhgn_msg_agg_ones_sorted_fwd(R, P, O, E, ptr(p), p.stride(0), ptr(q), q.stride(0), T, ptr(W), ptr(bb), ptr(oo), E, None, None, st))
+    out["msg_agg_fwd"] = entry("dhgn_msg_agg_ones_sorted_fwd: the update's critic obstacle relation, sort + prefix sums + binary search, O(log K) per pair",
+                               fl_alg, t, bound="valu", rows=R, note=note)
     return out
 
 

@@ -650,71 +650,76 @@ __global__ __launch_bounds__(512) void k_gru_seq_fwd(int T, int B, const float *
 // loops over 16-row tiles; the x and h tiles go through LDS in A-operand order (double buffered, the global loads of
 // the next tile are in flight during the MFMAs), r and z accumulate the input and the recurrent product in the same
 // accumulator, the gate math runs on the C layout with no exchange.
+// The contraction index is permuted: MFMA step s takes k = 32 q + s from lane (i, q) (any bijection of 0..127 works as long
+// as both operands use it).  A lane's 32 B-operand values of one weight row are then 128 CONTIGUOUS bytes, so the weights
+// go global -> registers with eight 16-byte loads per row (a wave reads 16 rows = 8 KB back to back) -- no LDS staging and
+// no barriers in the prologue, which used to be 15 of the launch's 83 us.
+constexpr int GC_LD = 36;  // 32 contraction steps + 4 pad floats per (q-plane, row)
+__device__ __forceinline__ int gc_idx(int row, int k) { return ((k >> 5) * GRU_RB + row) * GC_LD + (k & 31); }
+
 __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, const float *__restrict__ x, const float *__restrict__ hprev,
                                                   const float *__restrict__ w_ih, const float *__restrict__ w_hh,
                                                   const float *__restrict__ b_ih, const float *__restrict__ b_hh, float *__restrict__ hout) {
-    constexpr int TILE = 4 * GRU_RB * GRU_LD;
-    __shared__ __attribute__((aligned(16))) float smem[8 * 16 * GRU_H];  // 64 KB: weight staging, then the x / h tiles
-    float (*xs)[TILE] = (float (*)[TILE])smem;
-    float (*hs)[TILE] = (float (*)[TILE])(smem + 2 * TILE);
+    constexpr int TILE = 4 * GRU_RB * GC_LD;
+    __shared__ __attribute__((aligned(16))) float xs[2][TILE], hs[2][TILE];
+    __shared__ __attribute__((aligned(16))) float whn_s[8][TILE];  // W_hn B-operands of the 8 waves (64 KB), same layout as an A tile
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int c16 = l & 15, q = l >> 4;
     const int j = 16 * w + c16;
-    float wir[32], wiz[32], win[32], whr[32], whz[32], whn[32];
-    {   // weights -> registers through LDS: the 16 rows of one gate a wave needs are 8 KB contiguous in memory (coalesced
-        // 16-byte loads), lane (c16, q) then picks W[row c16][4 kk + q]; columns are XOR-swizzled by the row to spread banks
-        float *wb = smem + w * 16 * GRU_H;
-#define GRU_STAGE_W(dst, W, gate)                                                                        \
-        {                                                                                                \
-            const float4 *src = (const float4 *)((W) + (size_t)((gate) * GRU_H + 16 * w) * GRU_H);         \
-            _Pragma("unroll") for (int i = 0; i < 8; i++) {                                              \
-                const int idx = l + 64 * i, row = idx >> 5, col = (idx & 31) * 4;                        \
-                *(float4 *)(wb + row * GRU_H + (col ^ ((row & 7) * 4))) = src[idx];                      \
-            }                                                                                            \
-            __syncthreads();                                                                             \
-            _Pragma("unroll") for (int kk = 0; kk < 32; kk++) dst[kk] = wb[c16 * GRU_H + ((4 * kk + q) ^ ((c16 & 7) * 4))]; \
-            __syncthreads();                                                                             \
-        }
-        GRU_STAGE_W(wir, w_ih, 0) GRU_STAGE_W(wiz, w_ih, 1) GRU_STAGE_W(win, w_ih, 2)
-        GRU_STAGE_W(whr, w_hh, 0) GRU_STAGE_W(whz, w_hh, 1) GRU_STAGE_W(whn, w_hh, 2)
-#undef GRU_STAGE_W
+    // 160 weight registers per lane; the sixth slice (W_hn) is read from LDS every tile: 192 + accumulators + fragments do
+    // not fit the 256 registers of a 512-thread workgroup (the round-1 kernel spilled 19 registers to scratch)
+    float wir[32], wiz[32], win[32], whr[32], whz[32];
+#define GRU_LOAD_W(dst, W, gate)                                                                   \
+    {                                                                                              \
+        const float4 *src = (const float4 *)((W) + (size_t)((gate) * GRU_H + j) * GRU_H + 32 * q); \
+        _Pragma("unroll") for (int i = 0; i < 8; i++) {                                            \
+            const float4 v = src[i];                                                               \
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;     \
+        }                                                                                          \
     }
-    const float bir = b_ih[j], biz = b_ih[GRU_H + j], bin = b_ih[2 * GRU_H + j];
-    const float bhr = b_hh[j], bhz = b_hh[GRU_H + j], bhn = b_hh[2 * GRU_H + j];
-    // staging: thread e moves 4 consecutive k of one row (512 threads x float4 = one 16 x 128 tile)
+    GRU_LOAD_W(wir, w_ih, 0) GRU_LOAD_W(wiz, w_ih, 1) GRU_LOAD_W(win, w_ih, 2)
+    GRU_LOAD_W(whr, w_hh, 0) GRU_LOAD_W(whz, w_hh, 1)
+#undef GRU_LOAD_W
+    float *whn_l = &whn_s[w][(q * GRU_RB + c16) * GC_LD];  // this lane's 32 values of W_hh[2H + j][32 q ..]
+    {
+        const float4 *src = (const float4 *)(w_hh + (size_t)(2 * GRU_H + j) * GRU_H + 32 * q);
+#pragma unroll
+        for (int i = 0; i < 8; i++) *(float4 *)(whn_l + 4 * i) = src[i];
+    }
+    const float br = b_ih[j] + b_hh[j], bz = b_ih[GRU_H + j] + b_hh[GRU_H + j], bin = b_ih[2 * GRU_H + j], bhn = b_hh[2 * GRU_H + j];
+    // staging: thread e moves 4 consecutive k of one row (512 threads x float4 = one 16 x 128 tile), one 16-byte LDS store
     const int srow = tid >> 5, sk = (tid & 31) * 4;
-    const int sidx = (0 * GRU_RB + srow) * GRU_LD + (sk >> 2);  // plane (k & 3) adds GRU_RB * GRU_LD
-    float4 px, ph;
+    const int sidx = gc_idx(srow, sk);
+    float4 px = make_float4(0.f, 0.f, 0.f, 0.f), ph = px;
     int blk = blockIdx.x;
-    auto fetch = [&](int bk) {
-        const int row = bk * GRU_RB + srow;
-        if (row < B) {
-            px = *(const float4 *)(x + (size_t)row * GRU_H + sk);
-            ph = *(const float4 *)(hprev + (size_t)row * GRU_H + sk);
-        } else {
-            px = ph = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto stage = [&](int buf) {
-        float *xd = &xs[buf][sidx], *hd = &hs[buf][sidx];
-        xd[0] = px.x; xd[GRU_RB * GRU_LD] = px.y; xd[2 * GRU_RB * GRU_LD] = px.z; xd[3 * GRU_RB * GRU_LD] = px.w;
-        hd[0] = ph.x; hd[GRU_RB * GRU_LD] = ph.y; hd[2 * GRU_RB * GRU_LD] = ph.z; hd[3 * GRU_RB * GRU_LD] = ph.w;
-    };
-    if (blk < nblk) { fetch(blk); stage(0); }
+#define GRU_FETCH(bk)                                                             \
+    {                                                                             \
+        const int row_ = (bk) * GRU_RB + srow;                                     \
+        px = ph = make_float4(0.f, 0.f, 0.f, 0.f);                                 \
+        if (row_ < B) {                                                           \
+            px = *(const float4 *)(x + (size_t)row_ * GRU_H + sk);                 \
+            ph = *(const float4 *)(hprev + (size_t)row_ * GRU_H + sk);             \
+        }                                                                         \
+    }
+#define GRU_STAGE(buf) { *(float4 *)&xs[buf][sidx] = px; *(float4 *)&hs[buf][sidx] = ph; }
+    if (blk < nblk) { GRU_FETCH(blk) GRU_STAGE(0) }
     __syncthreads();
     int cur = 0;
     for (; blk < nblk; blk += gridDim.x) {
         const int nxt = blk + gridDim.x;
-        if (nxt < nblk) fetch(nxt);  // in flight during the MFMAs below
-        const float *xp = &xs[cur][(q * GRU_RB + c16) * GRU_LD];
-        const float *hp = &hs[cur][(q * GRU_RB + c16) * GRU_LD];
+        if (nxt < nblk) GRU_FETCH(nxt)  // in flight during the MFMAs below
+        const float *xp = &xs[cur][(q * GRU_RB + c16) * GC_LD];
+        const float *hp = &hs[cur][(q * GRU_RB + c16) * GC_LD];
         // r and z first (input and recurrent product in one accumulator each), then the two n products: the sigmoids of
         // r and z are VALU work the scheduler can run under the n-gate MFMAs
         f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, ain = ar, ahn = ar;
+        // fragments one k-group ahead, pinned with scheduling barriers: left alone, the scheduler hoists all sixteen LDS reads
+        // of a loop in front of it (64 more live registers) and spills weights
+        f32x4 ax = *(const f32x4 *)xp, ah = *(const f32x4 *)hp;
 #pragma unroll
         for (int k4 = 0; k4 < 8; k4++) {
-            const f32x4 ax = *(const f32x4 *)(xp + 4 * k4);
-            const f32x4 ah = *(const f32x4 *)(hp + 4 * k4);
+            f32x4 nax = ax, nah = ah;
+            if (k4 < 7) { nax = *(const f32x4 *)(xp + 4 * k4 + 4); nah = *(const f32x4 *)(hp + 4 * k4 + 4); }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 ar = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u], wir[4 * k4 + u], ar, 0, 0, 0);
@@ -722,35 +727,43 @@ __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, const float *
                 ar = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], whr[4 * k4 + u], ar, 0, 0, 0);
                 az = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], whz[4 * k4 + u], az, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            ax = nax; ah = nah;
         }
         float rg[4], zg[4];
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            rg[reg] = sigmoid_hw(ar[reg] + bir + bhr);
-            zg[reg] = sigmoid_hw(az[reg] + biz + bhz);
+            rg[reg] = sigmoid_hw(ar[reg] + br);
+            zg[reg] = sigmoid_hw(az[reg] + bz);
         }
+        ax = *(const f32x4 *)xp; ah = *(const f32x4 *)hp;
+        f32x4 bn = *(const f32x4 *)whn_l;
 #pragma unroll
         for (int k4 = 0; k4 < 8; k4++) {
-            const f32x4 ax = *(const f32x4 *)(xp + 4 * k4);
-            const f32x4 ah = *(const f32x4 *)(hp + 4 * k4);
+            f32x4 nax = ax, nah = ah, nbn = bn;
+            if (k4 < 7) { nax = *(const f32x4 *)(xp + 4 * k4 + 4); nah = *(const f32x4 *)(hp + 4 * k4 + 4); nbn = *(const f32x4 *)(whn_l + 4 * k4 + 4); }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 ain = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[u], win[4 * k4 + u], ain, 0, 0, 0);
-                ahn = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], whn[4 * k4 + u], ahn, 0, 0, 0);
+                ahn = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], bn[u], ahn, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            ax = nax; ah = nah; bn = nbn;
         }
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int row = 4 * q + reg;
-            const float hpv = hs[cur][gru_hidx(row, j)];
+            const float hpv = hs[cur][gc_idx(row, j)];
             const float r = rg[reg], z = zg[reg];
             const float n = tanh_hw(ain[reg] + bin + r * (ahn[reg] + bhn));
             if (blk * GRU_RB + row < B) hout[(size_t)(blk * GRU_RB + row) * GRU_H + j] = (1.f - z) * n + z * hpv;
         }
-        if (nxt < nblk) stage(cur ^ 1);  // the other buffer: its last readers passed the barrier of the previous tile
+        if (nxt < nblk) GRU_STAGE(cur ^ 1)  // the other buffer: its last readers passed the barrier of the previous tile
         __syncthreads();
         cur ^= 1;
     }
+#undef GRU_FETCH
+#undef GRU_STAGE
 }
 
 // backward of the sequence: dgi, dgh [T][B][3H] for the later weight-gradient GEMMs, dh0 [B][H].
