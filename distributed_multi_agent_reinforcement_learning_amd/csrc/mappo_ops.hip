@@ -174,6 +174,68 @@ __global__ void k_msg_agg3_fwd(MsgArgs a0, MsgArgs a1, MsgArgs a2, float *out0, 
     msg_agg_fwd_rows<PT>(a2, out2, smem);
 }
 
+// Actor and critic of one rollout tick in one pass.  The two networks share the encoder (DHGN/mappo_parallel.py:582-616: one
+// DHGN instance), so the messages ReLU(c_i - d_j) of a row are the same numbers for both; they differ only in the weights of
+// the mean: the actor's adjacency (float or packed rows) against the critic's ones over the first kv neighbours
+// (AttributeDataset :64-65; kv = K, or kvalid[row] in a batched rollout).  Each accumulator sees the additions
+// of the single-network loops above in the same order, so the results are bit-identical to two msg_agg_fwd_rows passes.
+template <int PT>
+__device__ __forceinline__ void msg_agg_pair_rows(const MsgArgs &a, bool c_valid, float *out_a, float *out_c, float *smem) {
+    const int P = a.P, K = a.K;
+    const MsgLds l = msg_lds(smem, P, K);
+    const int tid = threadIdx.x, f = tid;  // lane == feature
+    float w[8];
+    for (int k = 0; k < 8; k++) w[k] = 0.f;
+    for (int k = 0; k < a.din; k++) w[k] = a.W[(size_t)f * a.din + k];
+    const float bias = a.b[f];
+    const bool bits = a.adj_mode == MO_ADJ_BITS;
+    for (int r = blockIdx.x; r < a.R; r += gridDim.x) {
+        stage_row(a, r, l.p, l.q, l.adj, l.inv, l.pe, l.col, tid, blockDim.x);
+        const int kv = c_valid ? a.kvalid[r / a.q_div] : K;
+        float c[PT], acc[PT], acv[PT];
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            acc[i] = 0.f;
+            acv[i] = 0.f;
+            c[i] = 0.f;
+            if (i < P) {
+                c[i] = bias + w[0] * l.p[i * 4] + w[1] * l.p[i * 4 + 1] + w[2] * l.p[i * 4 + 2] + w[3] * l.p[i * 4 + 3];
+                if (a.din == 8) c[i] += w[4] * l.pe[i * 4] + w[5] * l.pe[i * 4 + 1] + w[6] * l.pe[i * 4 + 2] + w[7] * l.pe[i * 4 + 3];
+            }
+        }
+        for (int j = 0; j < K; j++) {
+            const unsigned int m = l.col[j];
+            const bool cj = j < kv;
+            if (m == 0u && !cj) continue;  // wave-uniform
+            const float4 qv = ((const float4 *)l.q)[j];
+            const float d = msg_dot4(w, qv);
+#pragma unroll
+            for (int i = 0; i < PT; i++) {
+                const float t = fmaxf(c[i] - d, 0.f);
+                if (cj) acv[i] += t;
+                if (m & (1u << i)) acc[i] = __builtin_fmaf(bits ? 1.f : l.adj[i * K + j], t, acc[i]);
+            }
+        }
+        const float inv_c = 1.f / fmaxf((float)kv, 1e-12f);
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            if (i < P) {
+                out_a[((size_t)r * P + i) * a.o_is + f] = acc[i] * l.inv[i];
+                out_c[((size_t)r * P + i) * a.o_is + f] = acv[i] * inv_c;
+            }
+        __syncthreads();
+    }
+}
+
+template <int PT>
+__global__ void k_msg_agg3_pair_fwd(MsgArgs a0, MsgArgs a1, MsgArgs a2, bool c_valid, float *out_a, float *out_c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int E = a0.E;
+    msg_agg_pair_rows<PT>(a0, false, out_a, out_c, smem);
+    msg_agg_pair_rows<PT>(a1, false, out_a + E, out_c + E, smem);
+    msg_agg_pair_rows<PT>(a2, c_valid, out_a + 2 * E, out_c + 2 * E, smem);
+}
+
 // partials: [gridDim.x][din + 1][E].  dW[:, k<4] = sum_i G_i p_i[k] - sum_j H_j q_j[k] with G_i = sum_j g_ij, H_j = sum_i g_ij,
 // g_ij = [z_ij > 0] abar_ij gout_i ; dW[:, 4+k] = sum_i G_i (p_i - e)[k] ; db = sum_i G_i.
 template <int PT>
@@ -451,6 +513,61 @@ __global__ void k_gae_norm(int64_t n, float *adv, const float *active, const dou
 }
 
 __global__ void k_advance_counter(uint64_t *ctr, uint64_t by) { *ctr += by; }
+
+// ---- spectral normalisation of a small head (torch.nn.utils.spectral_norm's pre-forward hook; reference value head :485) ------
+// n_iter power iterations  v = normalize(W^T u), u = normalize(W v)  in place, then sigma = u . (W v) and w_eff = W / sigma:
+// the hook's ~14 tiny launches per forward (two matrix-vector products, norms, clamps, divisions, clones, a dot) as one
+// workgroup.  normalize(x) = x / max(||x||_2, eps) as in F.normalize.  A <= SN_MAX_A rows, H <= SN_MAX_H columns.
+constexpr int SN_MAX_A = 16, SN_MAX_H = 1024;
+__global__ __launch_bounds__(256) void k_sn_power(int A, int H, const float *__restrict__ W, float *u, float *v, float eps, int n_iter,
+                                                  float *__restrict__ w_eff) {
+    __shared__ float s_u[SN_MAX_A], s_s[SN_MAX_A], s_v[SN_MAX_H], s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < A) s_u[tid] = u[tid];
+    for (int k = tid; k < H; k += 256) s_v[k] = v[k];
+    __syncthreads();
+    for (int it = 0; it <= n_iter; it++) {
+        if (it > 0) {  // v = normalize(W^T u)
+            float part = 0.f;
+            for (int k = tid; k < H; k += 256) {
+                float t = 0.f;
+                for (int a = 0; a < A; a++) t = __builtin_fmaf(W[(size_t)a * H + k], s_u[a], t);
+                s_v[k] = t;
+                part = __builtin_fmaf(t, t, part);
+            }
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) s_red[wave] = part;
+            __syncthreads();
+            const float den = fmaxf(sqrtf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])), eps);
+            for (int k = tid; k < H; k += 256) s_v[k] = s_v[k] / den;
+            __syncthreads();
+        }
+        // s = W v (needed for u and, with the final v, for sigma)
+        for (int a = wave; a < A; a += 4) {
+            float part = 0.f;
+            for (int k = lane; k < H; k += 64) part = __builtin_fmaf(W[(size_t)a * H + k], s_v[k], part);
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) s_s[a] = part;
+        }
+        __syncthreads();
+        if (it > 0) {  // u = normalize(s)
+            if (tid == 0) {
+                float q = 0.f;
+                for (int a = 0; a < A; a++) q = __builtin_fmaf(s_s[a], s_s[a], q);
+                const float den = fmaxf(sqrtf(q), eps);
+                for (int a = 0; a < A; a++) s_u[a] = s_s[a] / den;
+            }
+            __syncthreads();
+        }
+    }
+    float sigma = 0.f;
+    for (int a = 0; a < A; a++) sigma = __builtin_fmaf(s_u[a], s_s[a], sigma);
+    for (int i = tid; i < A * H; i += 256) w_eff[i] = W[i] / sigma;
+    if (n_iter > 0) {
+        if (tid < A) u[tid] = s_u[tid];
+        for (int k = tid; k < H; k += 256) v[k] = s_v[k];
+    }
+}
 
 // ---- Categorical sample / argmax ---------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *o) {
@@ -1172,6 +1289,31 @@ int dhgn_msg_agg3_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, co
     return (int)hipGetLastError();
 }
 
+int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_rs, const int32_t *o_kvalid,
+                           float *out_actor, float *out_critic, int64_t out_stride, void *stream) {
+    if (!rel || !p || !out_actor || !out_critic || R < 0) return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    MsgArgs a[3];
+    size_t lds = 0;
+    for (int r = 0; r < 3; r++) {
+        const mo_msg_rel &m = rel[r];
+        if (m.adj_mode != MO_ADJ_TENSOR && m.adj_mode != MO_ADJ_BITS) return MO_ERR_BAD_ARG;  // the actor's adjacency
+        int rc = check_msg(R, P, m.K, E, m.din, m.q_div, m.adj_mode, m.adj, nullptr, m.e);
+        if (rc) return rc;
+        if ((m.q_rs & 3) || out_stride < 3 * E) return MO_ERR_BAD_ARG;
+        a[r] = MsgArgs{R, P, m.K, E, m.din, m.q_div, m.adj_mode, p, m.q, m.e, (const float *)m.adj, p_rs, m.q_rs, m.e_rs, m.adj_rs, out_stride,
+                       r == 2 ? o_kvalid : nullptr, m.W, m.b};
+        const size_t l = msg_lds_bytes(P, m.K);
+        lds = l > lds ? l : lds;
+    }
+    const int grid = R < 8192 ? R : 8192;
+    const bool cv = o_kvalid != nullptr;
+    if (P <= 4) hipLaunchKernelGGL(k_msg_agg3_pair_fwd<4>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], cv, out_actor, out_critic);
+    else if (P <= 8) hipLaunchKernelGGL(k_msg_agg3_pair_fwd<8>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], cv, out_actor, out_critic);
+    else hipLaunchKernelGGL(k_msg_agg3_pair_fwd<16>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], cv, out_actor, out_critic);
+    return (int)hipGetLastError();
+}
+
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD_BLOCKS * (din + 1) * E * sizeof(float); }
 
 int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
@@ -1271,6 +1413,13 @@ int categorical_sample_counter(int32_t R, int32_t A, const float *probs, uint64_
     hipLaunchKernelGGL(k_categorical, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, A, probs, seed, (uint64_t)0, counter, greedy,
                        action, logp);
     hipLaunchKernelGGL(k_advance_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, (uint64_t)R);
+    return (int)hipGetLastError();
+}
+
+int spectral_norm_weight(int32_t A, int32_t H, const float *W, float *u, float *v, float eps, int32_t n_power_iterations, float *w_eff,
+                         void *stream) {
+    if (A < 1 || A > SN_MAX_A || H < 1 || H > SN_MAX_H || !W || !u || !v || !w_eff || n_power_iterations < 0) return MO_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_sn_power, dim3(1), dim3(256), 0, (hipStream_t)stream, A, H, W, u, v, eps, n_power_iterations, w_eff);
     return (int)hipGetLastError();
 }
 

@@ -311,11 +311,14 @@ class _RolloutState:
         quirk = agent.reference_quirks
         self.hist = z(max(d, 1), N, P, E)                    # shared list, hop k = hist[k]
         self.hist_c = None if quirk else z(max(d, 1), N, P, E)  # clean mode: actor uses hist, critic hist_c
-        self.a_cur, self.c_cur = z(N, P, E), z(N, P, E)
+        self.ac_cur = z(2, N, P, E)                          # this tick's embeddings: slot 0 actor, slot 1 critic
+        self.a_cur, self.c_cur = self.ac_cur[0], self.ac_cur[1]
         self.a_n = torch.zeros((N, P), dtype=torch.int32, device=dev)
         self.logp, self.v, self.raw = z(N, P), z(N, P), z(N, P)
         self.counter = torch.full((1,), int(agent.sample_rank) << 40, dtype=torch.int64, device=dev)  # position in the sampling stream (persists)
         self.graph = None
+        # one encoder pass per tick for both networks (DHGN.forward_pair): they hold the same DHGN instance (:582-616)
+        self.pair_forward = agent.actor.shared_net is agent.critic.shared_net
 
     def reset(self, env):
         for t in (self.ha, self.hc, self.hist, self.a_cur, self.c_cur):
@@ -353,8 +356,18 @@ class _RolloutState:
             hops_a = hops_c = []
         o = self._obs()
         # every result lands directly in the static rollout storage (no copies behind the model)
-        prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True, emb_out=self.a_cur)
-        v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True, emb_out=self.c_cur)  # the value head stays a module call (spectral-norm hook)
+        if self.pair_forward and not torch.is_grad_enabled():
+            # one encoder pass for both networks (they hold the same DHGN instance), then the two GRU trunks and heads
+            emb = ag.actor.shared_net.forward_pair(o["p_state"], o["e_state"], o["o_state"], o["p_adj"], o["e_adj"], o["o_adj_bits"],
+                                                   hops_a, hops_c, o["o_kvalid"], 1, self.ac_cur)
+            a_emb, c_emb = emb[0], emb[1]
+            feat_a, ha = ag.actor._rollout_features(a_emb, self.ha, True)
+            feat_c, hc = ag.critic._rollout_features(c_emb, self.hc, True)
+            prob = torch.softmax(ag.actor.head(feat_a), dim=-1)
+            v = ag.critic.head(feat_c)
+        else:
+            prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True, emb_out=self.a_cur)
+            v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True, emb_out=self.c_cur)
         if forced_actions is not None:
             self.a_n.copy_(forced_actions.to(torch.int32))
             self.logp.copy_(torch.distributions.Categorical(probs=prob).log_prob(forced_actions))

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
+from torch.nn.utils.spectral_norm import SpectralNorm
 
 from . import ops
 
@@ -106,6 +107,43 @@ class DHGN(nn.Module):
         h0 = self.encoder(p, e, o, adj_p, adj_e, adj_o, is_critic, o_kvalid, q_div, out if self.depth == 0 else None)
         return self.fcra(h0, hist, adj_p, is_critic, out)
 
+    # -- actor and critic of one rollout tick together ---------------------------------------------------------------------
+    # The critic is built on the actor's DHGN instance (DHGN/mappo_parallel.py:582-616), so in a rollout the two embeddings
+    # are the same layers applied to the same observation with two adjacencies (the observed one / ones).  forward_pair runs
+    # them as one batch of 2R rows: one message pass, one GEMM per layer instead of two, the position part of the semantic
+    # layer once.  Slot 0 = actor, slot 1 = critic; the numbers are those of forward(.., False) and forward(.., True).
+    def forward_pair(self, p, e, o, adj_p, adj_e, adj_o, hist_a, hist_c, o_kvalid=None, q_div=1, out=None):
+        """-> (2, R, P, E); out: static storage of that shape (rollout).  No autograd."""
+        R, P = p.shape[0], p.shape[1]
+        E, ind = self.embedding_dim, self.input_dim
+        M = self.MSG_layers
+        m3 = ops.msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
+                               o_kvalid, q_div)                                       # (2, R, P, 3, E)
+        agg0 = self.AGG_layers["AGG_vertex_0"]
+        emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)
+        Ws = self.semantic_layer.weight
+        h0 = out if (out is not None and self.depth == 0) else torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
+        o2 = h0.view(2, R * P, E)
+        torch.addmm(self.semantic_layer.bias, p.reshape(R * P, ind), Ws[:, :ind].t(), out=o2[0])   # position part: the same for both
+        o2[1].copy_(o2[0])
+        h0.view(2 * R * P, E).addmm_(emb.view(2 * R * P, 3 * E), Ws[:, ind:].t())
+        if self.depth == 0:
+            return h0
+        abar_a = F.normalize(adj_p, p=1, dim=-1)
+        abar_c = F.normalize(torch.ones_like(adj_p), p=1, dim=-1)
+        h = h0
+        for k in range(self.depth):
+            aggk = self.AGG_layers[f"AGG_fcra_{k}"]
+            nb = torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
+            torch.matmul(abar_a, hist_a[k], out=nb[0])
+            torch.matmul(abar_c, hist_c[k], out=nb[1])
+            agg = ops.linear(nb, aggk.weight, aggk.bias, relu=True)
+            Wf = self.FCRA_layers[k].weight
+            last = out is not None and k == self.depth - 1
+            h = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias), relu=True,
+                           out=out if last else None, consume_addend=not last)
+        return h
+
 
 def _o_adj(obs):
     """the obstacle adjacency of an observation dict: bit-packed rows (`o_adj_bits`, int32; what the env kernel emits and the
@@ -127,6 +165,19 @@ class _Trunk(nn.Module):
         h0 = torch.zeros(self.num_layers, batch * P, self.rnn_hidden_dim, dtype=x.dtype, device=x.device)
         feat, _ = ops.gru(x.contiguous(), h0, self.GRU)
         return feat.reshape(steps, batch, P, self.rnn_hidden_dim).permute(1, 0, 2, 3)
+
+    def head(self, feat):
+        """the output layer on GRU features.  A spectrally normalised head (the critic's, :485) outside autograd takes its
+        pre-forward hook -- power iteration on u, v in place, weight / sigma -- as one launch (ops.spectral_norm_weight)
+        instead of the hook's ~14; under autograd the module call (the hook differentiates through weight / sigma)."""
+        m = self.Mean
+        if not torch.is_grad_enabled() and feat.is_cuda:
+            for hook in m._forward_pre_hooks.values():
+                if isinstance(hook, SpectralNorm) and hook.name == "weight" and hook.dim == 0 and m.weight_orig.dim() == 2:
+                    w = ops.spectral_norm_weight(m.weight_orig, m.weight_u, m.weight_v, hook.eps,
+                                                 hook.n_power_iterations if m.training else 0)
+                    return F.linear(feat, w, m.bias)
+        return m(feat)
 
     def get_weights(self):
         return {k: v.cpu() for k, v in self.state_dict().items()}
@@ -191,7 +242,7 @@ class SharedCritic(_Trunk):
                               True, kvalid, obs.get("q_div", 1), emb_out)
         if mode == 0:
             feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)
-            return self.Mean(feat), hidden_state, emb
+            return self.head(feat), hidden_state, emb
         feat = self._sequence_features(emb, batch, steps)
         return self.Mean(feat)
 

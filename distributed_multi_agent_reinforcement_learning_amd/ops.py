@@ -37,6 +37,8 @@ def load_library():
         L.dhgn_msg_agg_fwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp]
         L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.dhgn_msg_agg3_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, i64, vp]
+        L.dhgn_msg_agg3_pair_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp]
+        L.spectral_norm_weight.argtypes = [i32, i32, vp, vp, vp, f32, i32, vp, vp]
         L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
         L.dhgn_msg_agg_bwd_workspace.restype = i64
         L.dhgn_msg_agg_ones_sorted_ok.argtypes = [i32] * 6
@@ -194,8 +196,8 @@ class MsgRel(C.Structure):
                 ("b", C.c_void_p)]
 
 
-def _msg3_call(L, p, rels, out, E):
-    """rels: three (q, e, adj, kvalid, W, b, adj_mode, q_div); one launch for the three relations"""
+def _msg3_rels(p, rels):
+    """the mo_msg_rel[3] of three (q, e, adj, kvalid, W, b, adj_mode, q_div)"""
     R, P = p.shape[0], p.shape[1]
     arr = (MsgRel * 3)()
     for r, (q, e, adj, kv, W, b, mode, qd) in enumerate(rels):
@@ -216,7 +218,53 @@ def _msg3_call(L, p, rels, out, E):
             m.kvalid = kv.data_ptr()
         m.W, m.b = W.data_ptr(), b.data_ptr()
     assert p.dtype == torch.float32 and p.shape[2] == 4 and _rows_ok(p)
-    _check(L.dhgn_msg_agg3_fwd(C.cast(arr, C.c_void_p), R, P, E, _ptr(p), p.stride(0), _ptr(out), 3 * E, _stream()), "dhgn_msg_agg3_fwd")
+    return arr
+
+
+def _msg3_call(L, p, rels, out, E):
+    """one launch for the three relations"""
+    arr = _msg3_rels(p, rels)
+    _check(L.dhgn_msg_agg3_fwd(C.cast(arr, C.c_void_p), p.shape[0], p.shape[1], E, _ptr(p), p.stride(0), _ptr(out), 3 * E, _stream()),
+           "dhgn_msg_agg3_fwd")
+
+
+def msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, o_kvalid=None, q_div=1, out=None):
+    """(2, R, P, 3, E): msg_agg3 of the actor (slot 0: the observed adjacency) and of the critic (slot 1: ones, for the obstacle
+    relation over the first o_kvalid[row] obstacles when given) from ONE pass over the messages -- the two networks share the
+    encoder weights (DHGN/mappo_parallel.py:582-616).  Rollout only (no autograd); bit-identical to two msg_agg3 calls."""
+    assert not (torch.is_grad_enabled() and any(t.requires_grad for t in (W0, b0, W1, b1, W2, b2))), "msg_agg3_pair has no backward"
+    L = load_library()
+    _need_gpu(p, "dhgn_msg_agg3_pair")
+    R, P = p.shape[0], p.shape[1]
+    E = W0.shape[0]
+    ws = [t.detach().contiguous() for t in (W0, b0, W1, b1, W2, b2)]
+    if out is None:
+        out = torch.empty((2, R, P, 3, E), dtype=torch.float32, device=p.device)
+    assert out.shape == (2, R, P, 3, E) and out.is_contiguous() and out.dtype == torch.float32
+    mode_o = ADJ_BITS if adj_o.dtype == torch.int32 else ADJ_TENSOR
+    arr = _msg3_rels(p, ((p, e.reshape(R, 4), adj_p, None, ws[0], ws[1], ADJ_TENSOR, 1), (e, None, adj_e, None, ws[2], ws[3], ADJ_TENSOR, 1),
+                         (o, None, adj_o, None, ws[4], ws[5], mode_o, q_div)))
+    if o_kvalid is not None:
+        assert o_kvalid.dtype == torch.int32 and o_kvalid.is_contiguous() and o_kvalid.shape[0] * q_div == R
+    _check(L.dhgn_msg_agg3_pair_fwd(C.cast(arr, C.c_void_p), R, P, E, _ptr(p), p.stride(0), _ptr(o_kvalid), _ptr(out[0]), _ptr(out[1]), 3 * E,
+                                    _stream()), "dhgn_msg_agg3_pair_fwd")
+    return out
+
+
+def spectral_norm_weight(weight_orig, u, v, eps=1e-12, n_power_iterations=1, out=None):
+    """torch.nn.utils.spectral_norm's pre-forward hook (SpectralNorm.compute_weight) for a small head as one launch: the power
+    iteration updates u and v IN PLACE (n_power_iterations = 0: the eval-mode form), returns weight_orig / sigma.  No autograd."""
+    L = load_library()
+    _need_gpu(weight_orig, "spectral_norm_weight")
+    A, H = weight_orig.shape
+    W = weight_orig.detach()
+    assert W.is_contiguous() and u.is_contiguous() and v.is_contiguous() and u.shape == (A,) and v.shape == (H,)
+    if out is None:
+        out = torch.empty_like(W)
+    assert out.shape == W.shape and out.is_contiguous()
+    _check(L.spectral_norm_weight(A, H, _ptr(W), _ptr(u), _ptr(v), float(eps), int(n_power_iterations), _ptr(out), _stream()),
+           "spectral_norm_weight")
+    return out
 
 
 SORTED_ONES_MIN_QDIV = 8  # rows sharing one neighbour set from which the sort + binary-search kernels beat the O(K) loop

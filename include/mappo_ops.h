@@ -57,6 +57,16 @@ typedef struct mo_msg_rel {
 } mo_msg_rel;
 int dhgn_msg_agg3_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_row_stride, float *out,
                       int64_t out_stride, void *stream);
+/*
+ * Actor AND critic of one rollout tick in one launch.  Both networks hold the same DHGN instance (mappo_parallel.py:582-616,
+ * critic built on the actor's shared_net), so the messages ReLU(W [p_i - q_j, ..] + b) are the same numbers; only the mean's
+ * weights differ: rel[r] carries the ACTOR's adjacency (MO_ADJ_TENSOR or MO_ADJ_BITS; rel[r].kvalid unused), the critic's is
+ * all ones (AttributeDataset :64-65) -- for the obstacle relation over the first o_kvalid[row / q_div] neighbours when
+ * o_kvalid != NULL (batched rollout), else over all K.  out_actor / out_critic [R][P][3][E], bit-identical to
+ * dhgn_msg_agg3_fwd called once per network.
+ */
+int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_row_stride,
+                           const int32_t *o_kvalid, float *out_actor, float *out_critic, int64_t out_stride, void *stream);
 
 /*
  * Backward of the above w.r.t. W and b (the inputs are data, they carry no gradient): recomputes the
@@ -111,6 +121,15 @@ int categorical_sample(int32_t R, int32_t A, const float *probs, uint64_t seed, 
  * captured in a hipGraph and replayed with fresh random numbers. */
 int categorical_sample_counter(int32_t R, int32_t A, const float *probs, uint64_t seed, uint64_t *counter, int32_t greedy,
                                int32_t *action, float *logp, void *stream);
+
+/*
+ * The pre-forward hook of torch.nn.utils.spectral_norm on a small head (the reference's value head, DHGN/mappo_parallel.py:485)
+ * as one launch: n_power_iterations times  v = normalize(W^T u), u = normalize(W v)  IN PLACE (as the hook does, also under
+ * no_grad), then sigma = u . (W v) and w_eff = W / sigma.  W, w_eff [A][H], u [A], v [H]; A <= 16, H <= 1024;
+ * normalize(x) = x / max(||x||_2, eps).  n_power_iterations = 0 is the hook's eval-mode form (u, v untouched).
+ */
+int spectral_norm_weight(int32_t A, int32_t H, const float *W, float *u, float *v, float eps, int32_t n_power_iterations, float *w_eff,
+                         void *stream);
 
 /*
  * torch.nn.GRU cell between the two MFMA GEMMs (reference DHGN/mappo_parallel.py:397,424,434; gate order r, z, n):

@@ -253,3 +253,29 @@ def test_train_full_gradient_tensors(name):
                 worst = (err / tol, f"{who}:{n} err {err:.3e} noise {noise:.3e} scale {scale:.3e}")
             assert err <= tol, (who, n, err, tol, noise, scale)
     print("worst gradient error / tolerance:", worst)
+
+
+@pytest.mark.parametrize("depth,quirks", [(0, True), (3, True), (2, False)])
+def test_paired_actor_critic_tick_equals_separate_forwards(depth, quirks):
+    """The rollout's joint actor+critic encoder pass (DHGN.forward_pair, fused spectral-norm head) against the two module
+    forwards: same actions injected, values / log-probs / stored embeddings agree to fp32 GEMM reordering noise."""
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import MAPPO
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from tests.helpers import product_cfg
+    bufs, acts = [], None
+    for pair in (True, False):
+        cfg = product_cfg(8, 40, 40, T=20, depth=depth, **{"runtime.use_graphs": False, "runtime.seed": 7, "runtime.reference_quirks": quirks})
+        torch.manual_seed(4)
+        agent = MAPPO(cfg, 5, 5, "Worker")
+        env = Pursuit_Env(cfg, num_envs=5)
+        st = agent._rollout_state(env)
+        assert st.pair_forward
+        st.pair_forward = pair
+        exp_r, rb, steps = agent.explore_env(env, 1, actions_override=acts)
+        bufs.append({k: v.clone() for k, v in rb.buffer.items() if k != "o_state"})
+        acts = rb.buffer["a_n"].clone()
+        sn = {k: v.clone() for k, v in agent.critic.state_dict().items() if k.endswith(("weight_u", "weight_v"))}
+        bufs[-1].update(sn)
+    for k in bufs[0]:
+        a, b = bufs[0][k].float(), bufs[1][k].float()
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (k, (a - b).abs().max())

@@ -420,3 +420,58 @@ def test_fused_three_relation_launch_equals_three_launches(critic):
             r1 = ops.msg_agg(p, e, None, adj_e, Ws[1], bs[1], mode)
             r2 = ops.msg_agg(p, o, None, ao, Ws[2], bs[2], mode_o, kv)
             assert torch.equal(fused, torch.stack((r0, r1, r2), 2))
+
+
+@pytest.mark.parametrize("P,K,q_div,valid", [(8, 176, 1, True), (4, 176, 1, True), (8, 176, 5, False), (15, 40, 1, True), (8, 33, 1, False)])
+def test_actor_critic_pair_launch_equals_two_launches(P, K, q_div, valid):
+    """dhgn_msg_agg3_pair_fwd (actor + critic of a rollout tick from one pass over the shared messages) against
+    dhgn_msg_agg3_fwd once per network: bit-identical, float and packed obstacle adjacency, with and without kvalid."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(11 + P + K)
+    Rq, E = 60, 128
+    R = Rq * q_div
+    p = (torch.randn(R, P, 4) * 10 + 20).cuda(); e = (torch.randn(R, 1, 4) * 10 + 20).cuda()
+    o = torch.zeros(Rq, K, 4); o[:, :, :2] = torch.randint(0, 40, (Rq, K, 2)).float(); o = o.cuda()
+    kv = torch.randint(0, K + 1, (Rq,), dtype=torch.int32).cuda()
+    kv[0] = 0; kv[1] = K
+    adj_p = (torch.rand(R, P, P) < 0.5).float().cuda(); adj_e = (torch.rand(R, P, 1) < 0.5).float().cuda()
+    adj_o = (torch.rand(R, P, K) < 0.1).float().cuda()
+    adj_o[2] = 0.0                                    # a row no agent sees anything in
+    adj_o[3, :, K - 1] = 1.0                          # an entry beyond most rows' kvalid
+    Ws = [(torch.randn(E, d) * 0.3).cuda() for d in (8, 4, 4)]; bs = [(torch.randn(E) * 0.1).cuda() for _ in range(3)]
+    wb = (Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2])
+    with torch.no_grad():
+        for ao in (adj_o, ops.pack_adj_bits(adj_o)):
+            pair = ops.msg_agg3_pair(p, e, o, adj_p, adj_e, ao, *wb, kv if valid else None, q_div)
+            actor = ops.msg_agg3(p, e, o, adj_p, adj_e, ao, *wb, False, None, q_div)
+            critic = ops.msg_agg3(p, e, o, adj_p, adj_e, ao, *wb, True, kv if valid else None, q_div)
+            assert torch.equal(pair[0], actor)
+            if q_div >= ops.SORTED_ONES_MIN_QDIV and not valid:   # the single-network call took the sorted kernels (reassociated sums)
+                assert torch.allclose(pair[1], critic, rtol=2e-5, atol=2e-5)
+            else:
+                assert torch.equal(pair[1], critic)
+
+
+@pytest.mark.parametrize("A,H", [(1, 128), (9, 128), (16, 1000)])
+def test_spectral_norm_weight_matches_torch_hook(A, H):
+    """spectral_norm_weight (one launch) against torch.nn.utils.spectral_norm's hook on the CPU in float64: the same u, v
+    trajectory over several forwards (in-place power iteration, also under no_grad) and the same weight / sigma; the
+    eval-mode form leaves u, v untouched."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(A * 1000 + H)
+    lin = torch.nn.utils.spectral_norm(torch.nn.Linear(H, A)).double()
+    W = lin.weight_orig.detach().float().cuda().contiguous()
+    u, v = lin.weight_u.detach().float().cuda().clone(), lin.weight_v.detach().float().cuda().clone()
+    x = torch.randn(5, H, dtype=torch.float64)
+    with torch.no_grad():
+        for it in range(4):
+            lin(x)                                     # hook: power iteration in place, weight = W / sigma
+            w = ops.spectral_norm_weight(W, u, v, 1e-12, 1)
+            assert torch.allclose(w.cpu().double(), lin.weight.detach(), rtol=2e-5, atol=1e-7), it
+            assert torch.allclose(u.cpu().double(), lin.weight_u, rtol=0, atol=2e-5) and torch.allclose(v.cpu().double(), lin.weight_v, rtol=0, atol=2e-5)
+        lin.eval()
+        u0, v0 = u.clone(), v.clone()
+        lin(x)
+        w = ops.spectral_norm_weight(W, u, v, 1e-12, 0)
+        assert torch.equal(u, u0) and torch.equal(v, v0)
+        assert torch.allclose(w.cpu().double(), lin.weight.detach(), rtol=2e-5, atol=1e-7)
