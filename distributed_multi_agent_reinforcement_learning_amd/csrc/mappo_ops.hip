@@ -2,8 +2,8 @@
 //
 // dhgn_msg_agg_{fwd,bwd}: the relation message ReLU(W (p_i - q_j) + b) and its adjacency-weighted mean are fused so
 // the (rows, P, K, E) message tensor (865 MB per reference mini-batch) never exists; backward recomputes the
-// pre-activation.  One workgroup of E lanes (E/64 wavefronts) walks rows; lane = output feature, so the adjacency
-// test is wave-uniform (sparse LiDAR rows skip ~80 % of the neighbours) and p/q/adj are LDS broadcasts.
+// pre-activation.  Lane = output feature; a row's positions / adjacency / neighbour coordinates are wave-uniform and live in
+// registers read back with v_readlane (or come through scalar loads): no LDS, no barriers (section "relation message + mean").
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -14,302 +14,423 @@ namespace {
 
 constexpr int MAX_P = 16;
 
-struct MsgArgs {
-    int R, P, K, E, din, q_div, adj_mode;
-    const float *p, *q, *e, *adj;  // adj: float [R][P][K], or uint32 words (MO_ADJ_BITS)
-    int64_t p_rs, q_rs, e_rs, adj_rs;  // row strides in elements (rows may be slices of (N, T, ...) buffers)
-    int64_t o_is;                       // elements between consecutive (row, agent) vectors of out / gout
-    const int32_t *kvalid;
-    const float *W, *b;
-};
-
-// stages one row (p, q, adjacency) in LDS; s_inv[P] = 1 / L1-norm per agent, s_col[K] = bit i set iff adj[i][j] != 0
-__device__ __forceinline__ void stage_row(const MsgArgs &a, int r, float *s_p, float *s_q, float *s_adj, float *s_inv, float *s_pe,
-                                          unsigned int *s_col, int tid, int nthr) {
-    const int P = a.P, K = a.K;
-    const int qr = r / a.q_div;
-    for (int i = tid; i < P * 4; i += nthr) s_p[i] = a.p[(size_t)r * a.p_rs + i];
-    {
-        const float4 *src = (const float4 *)(a.q + (size_t)qr * a.q_rs);
-        float4 *dst = (float4 *)s_q;
-        for (int i = tid; i < K; i += nthr) dst[i] = src[i];
-    }
-    const int RWK = MO_ADJ_ROW_WORDS(K);
-    if (a.adj_mode == MO_ADJ_TENSOR) {
-        const float *src = a.adj + (size_t)r * a.adj_rs;
-        if (((P * K) & 3) == 0 && (a.adj_rs & 3) == 0) {
-            for (int i = tid; i < (P * K) >> 2; i += nthr) ((float4 *)s_adj)[i] = ((const float4 *)src)[i];
-        } else {
-            for (int i = tid; i < P * K; i += nthr) s_adj[i] = src[i];
-        }
-    } else if (a.adj_mode == MO_ADJ_BITS) {  // P rows of RWK words: 1/29 of the bytes of the float adjacency
-        const uint32_t *src = (const uint32_t *)a.adj + (size_t)r * a.adj_rs;
-        for (int i = tid; i < P * RWK; i += nthr) ((uint32_t *)s_adj)[i] = src[i];
-    }
-    __syncthreads();
-    if (a.adj_mode == MO_ADJ_TENSOR) {
-        for (int j = tid; j < K; j += nthr) {
-            unsigned int m = 0;
-            for (int i = 0; i < P; i++) m |= (s_adj[i * K + j] != 0.f) ? (1u << i) : 0u;
-            s_col[j] = m;
-        }
-    } else if (a.adj_mode == MO_ADJ_BITS) {
-        const uint32_t *sw = (const uint32_t *)s_adj;
-        for (int j = tid; j < K; j += nthr) {
-            unsigned int m = 0;
-            for (int i = 0; i < P; i++) m |= ((sw[i * RWK + (j >> 5)] >> (j & 31)) & 1u) << i;
-            s_col[j] = m;
-        }
-    }
-    if (tid < P) {
-        float s = 0.f;
-        if (a.adj_mode == MO_ADJ_TENSOR) {
-            for (int j = 0; j < K; j++) s += fabsf(s_adj[tid * K + j]);
-        } else if (a.adj_mode == MO_ADJ_BITS) {  // sum of K ones and zeros: exact in fp32, any order
-            const uint32_t *sw = (const uint32_t *)s_adj;
-            int cnt = 0;
-            for (int w = 0; w < (K + 31) >> 5; w++) cnt += __popc(sw[tid * RWK + w] & ((w == (K >> 5)) ? ((1u << (K & 31)) - 1u) : 0xFFFFFFFFu));
-            s = (float)cnt;
-        } else if (a.adj_mode == MO_ADJ_ONES) {
-            s = (float)K;
-        } else {
-            s = (float)a.kvalid[qr];
-        }
-        s_inv[tid] = 1.f / fmaxf(s, 1e-12f);
-        if (a.din == 8) {
-            for (int k = 0; k < 4; k++) s_pe[tid * 4 + k] = s_p[tid * 4 + k] - a.e[(size_t)r * a.e_rs + k];
-        }
-    }
-    __syncthreads();
-}
-
-__host__ __device__ inline int msg_adj_floats(int P, int K) {  // the adjacency stage holds float [P][K] or packed rows
-    const int f = (P * K + 3) & ~3, w = P * MO_ADJ_ROW_WORDS(K);
-    return f > w ? f : w;
-}
 // d_j = W[:, :4] q_j with a fixed evaluation order (explicit fused multiply-adds: every loop variant rounds identically)
 __device__ __forceinline__ float msg_dot4(const float *w, const float4 &qv) {
     return __builtin_fmaf(w[3], qv.w, __builtin_fmaf(w[2], qv.z, __builtin_fmaf(w[1], qv.y, w[0] * qv.x)));
 }
-struct MsgLds { float *q, *adj, *p, *pe, *inv; unsigned int *col; };
-__device__ __forceinline__ MsgLds msg_lds(float *smem, int P, int K) {
-    MsgLds l;
-    l.q = smem;
-    l.adj = l.q + K * 4;
-    l.p = l.adj + msg_adj_floats(P, K);
-    l.pe = l.p + P * 4;
-    l.inv = l.pe + P * 4;
-    l.col = (unsigned int *)(l.inv + MAX_P);
-    return l;
+
+// The pre-activation of the relation message is evaluated as z_ij = c_i - d_j with c_i = b + W[:, :4] p_i (+ W[:, 4:8] (p_i - e))
+// and d_j = W[:, :4] q_j; lane = output feature, one accumulator per agent in registers (PT = P rounded up to 8 or 16).
+// ---- relation message + mean (dhgn_msg_agg_*) -------------------------------------------------------------------------
+// No LDS, no barriers.  Everything a row needs besides the per-lane feature weights is wave-uniform (positions, adjacency,
+// neighbour coordinates): each of these small arrays is fetched with ONE coalesced load (lane l holds element l) and read back
+// with v_readlane, or -- the obstacle coordinates, K x 16 bytes shared by the rows of an episode -- through uniform addresses
+// (scalar loads); the loads of row r+1 are issued before row r is computed, and every wave walks its rows on its own.
+// A packed LiDAR adjacency row (MO_ADJ_BITS: ~18 of 176 columns set per row, ~2 per agent) is walked bit by bit per agent
+// (s_ff1), so the loop length is the number of edges, not K; float adjacencies and the all-ones forms keep the column loop
+// with d_j shared by the agents.  Every accumulator receives its additions in ascending j in all forms, so packed and float
+// adjacency, single and paired launches give bit-identical forward results.  Rows are dealt to workgroups in contiguous
+// chunks (rows of one episode share their obstacle set: scalar-cache hits).
+//   QS: the neighbour coordinates of a row fit one register (4 K <= 64);  AS: so does its adjacency (float: P K <= 64;
+//   packed: P MO_ADJ_ROW_WORDS(K) <= 128, two registers); otherwise these are read through uniform addresses.
+struct MsgDims {
+    int R, P, K, E, din, q_div, adj_mode, rpb;  // rpb: rows per workgroup
+    int64_t p_rs, q_rs, e_rs, adj_rs, o_is;
+};
+
+__device__ __forceinline__ float rl_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ uint32_t rl_u(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+
+struct MsgRow {
+    float vp, ve, vq;   // p row [4 P], e row [4], q row [4 K] (QS)
+    uint32_t va0, va1;  // adjacency (AS): float bits [P][K], or packed words [P][RWK] (va1: words 64..127)
+    int kv;             // critic: number of neighbours averaged over
+};
+
+template <bool QS, bool AS>
+__device__ __forceinline__ MsgRow msgw_load(const MsgDims &d, int r, const float *__restrict__ p, const float *__restrict__ q,
+                                            const float *__restrict__ e, const void *__restrict__ adj, const int32_t *__restrict__ kvalid,
+                                            bool use_kvalid) {
+    const int lane = threadIdx.x & 63, qr = r / d.q_div;
+    MsgRow m;
+    m.vp = lane < 4 * d.P ? p[(size_t)r * d.p_rs + lane] : 0.f;
+    m.ve = (d.din == 8 && lane < 4) ? e[(size_t)r * d.e_rs + lane] : 0.f;
+    m.vq = 0.f;
+    if (QS) m.vq = lane < 4 * d.K ? q[(size_t)qr * d.q_rs + lane] : 0.f;
+    m.va0 = m.va1 = 0u;
+    if (AS) {
+        if (d.adj_mode == MO_ADJ_TENSOR) {
+            m.va0 = lane < d.P * d.K ? __float_as_uint(((const float *)adj)[(size_t)r * d.adj_rs + lane]) : 0u;
+        } else if (d.adj_mode == MO_ADJ_BITS) {
+            const uint32_t *bw = (const uint32_t *)adj + (size_t)r * d.adj_rs;
+            const int n = d.P * MO_ADJ_ROW_WORDS(d.K);
+            m.va0 = lane < n ? bw[lane] : 0u;
+            m.va1 = lane + 64 < n ? bw[lane + 64] : 0u;
+        }
+    }
+    m.kv = use_kvalid ? kvalid[qr] : d.K;
+    return m;
 }
 
-// The pre-activation is evaluated as z_ij = c_i - d_j with c_i = b + W[:, :4] p_i (+ W[:, 4:8] (p_i - e)) and
-// d_j = W[:, :4] q_j: d_j is shared by the P agents of a row, so the loop runs j-outer / i-inner with one
-// accumulator per agent in registers (PT = P rounded up to 4, 8 or 16).  Neighbour columns no agent sees are skipped
-// (wave-uniform), which removes ~60 % of the obstacle columns of LiDAR adjacency rows.
+template <bool QS>
+__device__ __forceinline__ float4 msgw_q(const MsgRow &m, const float4 *__restrict__ q4, int j) {
+    if (QS) return make_float4(rl_f(m.vq, 4 * j), rl_f(m.vq, 4 * j + 1), rl_f(m.vq, 4 * j + 2), rl_f(m.vq, 4 * j + 3));
+    return q4[j];
+}
+template <bool AS>
+__device__ __forceinline__ uint32_t msgw_word(const MsgRow &m, const uint32_t *__restrict__ bw, int idx) {
+    if (AS) return idx < 64 ? rl_u(m.va0, idx) : rl_u(m.va1, idx - 64);
+    return bw[idx];
+}
+
+// non-zero pattern of a float adjacency held in va0 (lane i K + j): nz; col = the bits i K of all agents; zero_one: every
+// non-zero entry is exactly 1.0f (the environments' adjacencies), so weights need no read-back and a row's L1 norm is its
+// popcount (a sum of ones is exact in any order: the same value as the sequential sum)
+struct MsgMask { uint64_t nz, col; bool zero_one; };
+__device__ __forceinline__ MsgMask msgw_mask(const MsgRow &m, int P, int K) {
+    const float a = __uint_as_float(m.va0);
+    MsgMask k;
+    k.nz = __ballot(a != 0.f);
+    k.zero_one = __ballot(a != 0.f && a != 1.f) == 0ull;
+    k.col = 0ull;
+    for (int i = 0; i < P; i++) k.col |= 1ull << (i * K);
+    return k;
+}
+__device__ __forceinline__ float msgw_row_norm(const MsgRow &m, const MsgMask &k, int i, int K) {
+    if (k.zero_one) return (float)__popcll((k.nz >> (i * K)) & ((K >= 64) ? ~0ull : ((1ull << K) - 1ull)));
+    float s = 0.f;
+    for (int j = 0; j < K; j++) s += fabsf(__uint_as_float(rl_u(m.va0, i * K + j)));
+    return s;
+}
+
 template <int PT>
-__device__ __forceinline__ void msg_agg_fwd_rows(const MsgArgs &a, float *out, float *smem) {
-    const int P = a.P, K = a.K, E = a.E;
-    const MsgLds l = msg_lds(smem, P, K);
-    const int tid = threadIdx.x, f = tid;  // lane == feature
-    float w[8];
-    for (int k = 0; k < 8; k++) w[k] = 0.f;
-    for (int k = 0; k < a.din; k++) w[k] = a.W[(size_t)f * a.din + k];
-    const float bias = a.b[f];
-    for (int r = blockIdx.x; r < a.R; r += gridDim.x) {
-        stage_row(a, r, l.p, l.q, l.adj, l.inv, l.pe, l.col, tid, blockDim.x);
-        int kv = K;
-        if (a.adj_mode == MO_ADJ_VALID) kv = a.kvalid[r / a.q_div];
-        float c[PT], acc[PT];
+__device__ __forceinline__ void msgw_center(const MsgDims &d, const MsgRow &m, const float (&w)[8], float bias, float (&c)[PT]) {
+    const float e0 = rl_f(m.ve, 0), e1 = rl_f(m.ve, 1), e2 = rl_f(m.ve, 2), e3 = rl_f(m.ve, 3);
 #pragma unroll
-        for (int i = 0; i < PT; i++) {
-            acc[i] = 0.f;
-            c[i] = 0.f;
-            if (i < P) {
-                c[i] = bias + w[0] * l.p[i * 4] + w[1] * l.p[i * 4 + 1] + w[2] * l.p[i * 4 + 2] + w[3] * l.p[i * 4 + 3];
-                if (a.din == 8) c[i] += w[4] * l.pe[i * 4] + w[5] * l.pe[i * 4 + 1] + w[6] * l.pe[i * 4 + 2] + w[7] * l.pe[i * 4 + 3];
-            }
+    for (int i = 0; i < PT; i++) {
+        c[i] = 0.f;
+        if (i < d.P) {
+            const float p0 = rl_f(m.vp, 4 * i), p1 = rl_f(m.vp, 4 * i + 1), p2 = rl_f(m.vp, 4 * i + 2), p3 = rl_f(m.vp, 4 * i + 3);
+            c[i] = bias + w[0] * p0 + w[1] * p1 + w[2] * p2 + w[3] * p3;
+            if (d.din == 8) c[i] += w[4] * (p0 - e0) + w[5] * (p1 - e1) + w[6] * (p2 - e2) + w[7] * (p3 - e3);
         }
-        if (a.adj_mode == MO_ADJ_TENSOR || a.adj_mode == MO_ADJ_BITS) {
-            // one instruction stream for both adjacency forms (a packed entry is the weight 1.f), so they agree bit for bit
-            const bool bits = a.adj_mode == MO_ADJ_BITS;
-            for (int j = 0; j < K; j++) {
-                const unsigned int m = l.col[j];
-                if (m == 0u) continue;  // wave-uniform
-                const float4 qv = ((const float4 *)l.q)[j];
-                const float d = msg_dot4(w, qv);
-#pragma unroll
-                for (int i = 0; i < PT; i++)
-                    if (m & (1u << i)) acc[i] = __builtin_fmaf(bits ? 1.f : l.adj[i * K + j], fmaxf(c[i] - d, 0.f), acc[i]);
-            }
-        } else {
-            for (int j = 0; j < kv; j++) {
-                const float4 qv = ((const float4 *)l.q)[j];
-                const float d = msg_dot4(w, qv);
-#pragma unroll
-                for (int i = 0; i < PT; i++) acc[i] += fmaxf(c[i] - d, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < PT; i++)
-            if (i < P) out[((size_t)r * P + i) * a.o_is + f] = acc[i] * l.inv[i];
-        __syncthreads();
     }
 }
 
-template <int PT>
-__global__ void k_msg_agg_fwd(MsgArgs a, float *out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    msg_agg_fwd_rows<PT>(a, out, smem);
-}
-
-// The three relations of DHGN.encoder (defender, evader, obstacle; DHGN/mappo_parallel.py:256-281) in ONE launch: every
-// workgroup walks its rows three times, once per relation.  The rollout's per-tick calls handle 4096 rows each, ~15-60 us of
-// mostly launch ramp and staging latency per kernel; one launch instead of three keeps the workgroups resident.
-template <int PT>
-__global__ void k_msg_agg3_fwd(MsgArgs a0, MsgArgs a1, MsgArgs a2, float *out0, float *out1, float *out2) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    msg_agg_fwd_rows<PT>(a0, out0, smem);
-    msg_agg_fwd_rows<PT>(a1, out1, smem);
-    msg_agg_fwd_rows<PT>(a2, out2, smem);
-}
-
-// Actor and critic of one rollout tick in one pass.  The two networks share the encoder (DHGN/mappo_parallel.py:582-616: one
-// DHGN instance), so the messages ReLU(c_i - d_j) of a row are the same numbers for both; they differ only in the weights of
-// the mean: the actor's adjacency (float or packed rows) against the critic's ones over the first kv neighbours
-// (AttributeDataset :64-65; kv = K, or kvalid[row] in a batched rollout).  Each accumulator sees the additions
-// of the single-network loops above in the same order, so the results are bit-identical to two msg_agg_fwd_rows passes.
-template <int PT>
-__device__ __forceinline__ void msg_agg_pair_rows(const MsgArgs &a, bool c_valid, float *out_a, float *out_c, float *smem) {
-    const int P = a.P, K = a.K;
-    const MsgLds l = msg_lds(smem, P, K);
-    const int tid = threadIdx.x, f = tid;  // lane == feature
-    float w[8];
-    for (int k = 0; k < 8; k++) w[k] = 0.f;
-    for (int k = 0; k < a.din; k++) w[k] = a.W[(size_t)f * a.din + k];
-    const float bias = a.b[f];
-    const bool bits = a.adj_mode == MO_ADJ_BITS;
-    for (int r = blockIdx.x; r < a.R; r += gridDim.x) {
-        stage_row(a, r, l.p, l.q, l.adj, l.inv, l.pe, l.col, tid, blockDim.x);
-        const int kv = c_valid ? a.kvalid[r / a.q_div] : K;
-        float c[PT], acc[PT], acv[PT];
+// the actor's aggregate of one row: acc[i] = sum_j adj_ij relu(c_i - d_j), inv[i] = 1 / max(sum_j |adj_ij|, 1e-12)
+template <int PT, bool QS, bool AS>
+__device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const MsgRow &m, const float4 *__restrict__ q4,
+                                               const void *__restrict__ adj, const float (&w)[8], const float (&c)[PT], float (&acc)[PT],
+                                               float (&inv)[PT]) {
+    const int P = d.P, K = d.K;
+    if (d.adj_mode == MO_ADJ_BITS) {
+        const uint32_t *__restrict__ bw = (const uint32_t *)adj + (size_t)r * d.adj_rs;
+        const int nw = (K + 31) >> 5, RWK = MO_ADJ_ROW_WORDS(K);
 #pragma unroll
         for (int i = 0; i < PT; i++) {
             acc[i] = 0.f;
-            acv[i] = 0.f;
-            c[i] = 0.f;
+            inv[i] = 0.f;
             if (i < P) {
-                c[i] = bias + w[0] * l.p[i * 4] + w[1] * l.p[i * 4 + 1] + w[2] * l.p[i * 4 + 2] + w[3] * l.p[i * 4 + 3];
-                if (a.din == 8) c[i] += w[4] * l.pe[i * 4] + w[5] * l.pe[i * 4 + 1] + w[6] * l.pe[i * 4 + 2] + w[7] * l.pe[i * 4 + 3];
+                int cnt = 0;
+                for (int wd = 0; wd < nw; wd++) {
+                    uint32_t bits = msgw_word<AS>(m, bw, i * RWK + wd);
+                    if (wd == (K >> 5)) bits &= (1u << (K & 31)) - 1u;
+                    cnt += __popc(bits);
+                    while (bits) {
+                        const int j = (wd << 5) + __builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        acc[i] += fmaxf(c[i] - msg_dot4(w, msgw_q<QS>(m, q4, j)), 0.f);
+                    }
+                }
+                inv[i] = 1.f / fmaxf((float)cnt, 1e-12f);
+            }
+        }
+    } else if (AS) {  // MO_ADJ_TENSOR held in one register: the non-zero pattern as a 64-bit mask (bit i K + j)
+        const MsgMask k = msgw_mask(m, P, K);
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            acc[i] = 0.f;
+            inv[i] = 0.f;
+            if (i < P) inv[i] = 1.f / fmaxf(msgw_row_norm(m, k, i, K), 1e-12f);
+        }
+        for (int j = 0; j < K; j++) {
+            const uint64_t cm = (k.nz >> j) & k.col;  // bit i K: agent i sees neighbour j
+            if (cm == 0ull) continue;
+            const float dj = msg_dot4(w, msgw_q<QS>(m, q4, j));
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+                if (i < P && ((cm >> (i * K)) & 1ull)) {
+                    const float aij = k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, i * K + j));
+                    acc[i] = __builtin_fmaf(aij, fmaxf(c[i] - dj, 0.f), acc[i]);
+                }
+        }
+    } else {  // MO_ADJ_TENSOR read through uniform addresses
+        const float *__restrict__ ar = (const float *)adj + (size_t)r * d.adj_rs;
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            acc[i] = 0.f;
+            inv[i] = 0.f;
+            if (i < P) {
+                float s = 0.f;
+                for (int j = 0; j < K; j++) s += fabsf(ar[i * K + j]);
+                inv[i] = 1.f / fmaxf(s, 1e-12f);
             }
         }
         for (int j = 0; j < K; j++) {
-            const unsigned int m = l.col[j];
-            const bool cj = j < kv;
-            if (m == 0u && !cj) continue;  // wave-uniform
-            const float4 qv = ((const float4 *)l.q)[j];
-            const float d = msg_dot4(w, qv);
+            bool any = false;
+            for (int i = 0; i < P; i++) any |= ar[i * K + j] != 0.f;
+            if (!any) continue;
+            const float dj = msg_dot4(w, msgw_q<QS>(m, q4, j));
 #pragma unroll
-            for (int i = 0; i < PT; i++) {
-                const float t = fmaxf(c[i] - d, 0.f);
-                if (cj) acv[i] += t;
-                if (m & (1u << i)) acc[i] = __builtin_fmaf(bits ? 1.f : l.adj[i * K + j], t, acc[i]);
-            }
+            for (int i = 0; i < PT; i++)
+                if (i < P) {
+                    const float aij = ar[i * K + j];
+                    if (aij != 0.f) acc[i] = __builtin_fmaf(aij, fmaxf(c[i] - dj, 0.f), acc[i]);
+                }
         }
-        const float inv_c = 1.f / fmaxf((float)kv, 1e-12f);
-#pragma unroll
-        for (int i = 0; i < PT; i++)
-            if (i < P) {
-                out_a[((size_t)r * P + i) * a.o_is + f] = acc[i] * l.inv[i];
-                out_c[((size_t)r * P + i) * a.o_is + f] = acv[i] * inv_c;
-            }
-        __syncthreads();
     }
 }
 
-template <int PT>
-__global__ void k_msg_agg3_pair_fwd(MsgArgs a0, MsgArgs a1, MsgArgs a2, bool c_valid, float *out_a, float *out_c) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int E = a0.E;
-    msg_agg_pair_rows<PT>(a0, false, out_a, out_c, smem);
-    msg_agg_pair_rows<PT>(a1, false, out_a + E, out_c + E, smem);
-    msg_agg_pair_rows<PT>(a2, c_valid, out_a + 2 * E, out_c + 2 * E, smem);
-}
-
-// partials: [gridDim.x][din + 1][E].  dW[:, k<4] = sum_i G_i p_i[k] - sum_j H_j q_j[k] with G_i = sum_j g_ij, H_j = sum_i g_ij,
-// g_ij = [z_ij > 0] abar_ij gout_i ; dW[:, 4+k] = sum_i G_i (p_i - e)[k] ; db = sum_i G_i.
-template <int PT>
-__global__ void k_msg_agg_bwd(MsgArgs a, const float *gout, float *partials) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int P = a.P, K = a.K, E = a.E;
-    const MsgLds l = msg_lds(smem, P, K);
-    const int tid = threadIdx.x, f = tid;
-    float w[8], gw[8];
-    for (int k = 0; k < 8; k++) { w[k] = 0.f; gw[k] = 0.f; }
-    for (int k = 0; k < a.din; k++) w[k] = a.W[(size_t)f * a.din + k];
-    const float bias = a.b[f];
-    float gb = 0.f;
-    for (int r = blockIdx.x; r < a.R; r += gridDim.x) {
-        stage_row(a, r, l.p, l.q, l.adj, l.inv, l.pe, l.col, tid, blockDim.x);
-        int kv = K;
-        if (a.adj_mode == MO_ADJ_VALID) kv = a.kvalid[r / a.q_div];
-        float c[PT], gi[PT], G[PT];
+// the critic's aggregate: ones over the first kv neighbours (coordinates fetched four columns at a time)
+template <int PT, bool QS>
+__device__ __forceinline__ void msgw_ones_row(int kv, const MsgRow &m, const float4 *__restrict__ q4, const float (&w)[8], const float (&c)[PT],
+                                              float (&acc)[PT]) {
 #pragma unroll
-        for (int i = 0; i < PT; i++) {
-            G[i] = 0.f; c[i] = 0.f; gi[i] = 0.f;
-            if (i < P) {
-                c[i] = bias + w[0] * l.p[i * 4] + w[1] * l.p[i * 4 + 1] + w[2] * l.p[i * 4 + 2] + w[3] * l.p[i * 4 + 3];
-                if (a.din == 8) c[i] += w[4] * l.pe[i * 4] + w[5] * l.pe[i * 4 + 1] + w[6] * l.pe[i * 4 + 2] + w[7] * l.pe[i * 4 + 3];
-                gi[i] = gout[((size_t)r * P + i) * a.o_is + f] * l.inv[i];
+    for (int i = 0; i < PT; i++) acc[i] = 0.f;
+    int j = 0;
+    if (!QS) {
+        for (; j + 4 <= kv; j += 4) {
+            const float4 qa = q4[j], qb = q4[j + 1], qc = q4[j + 2], qd = q4[j + 3];
+            const float da = msg_dot4(w, qa), db = msg_dot4(w, qb), dc = msg_dot4(w, qc), dd = msg_dot4(w, qd);
+#pragma unroll
+            for (int i = 0; i < PT; i++) {
+                acc[i] += fmaxf(c[i] - da, 0.f);
+                acc[i] += fmaxf(c[i] - db, 0.f);
+                acc[i] += fmaxf(c[i] - dc, 0.f);
+                acc[i] += fmaxf(c[i] - dd, 0.f);
             }
         }
+    }
+    for (; j < kv; j++) {
+        const float dj = msg_dot4(w, msgw_q<QS>(m, q4, j));
+#pragma unroll
+        for (int i = 0; i < PT; i++) acc[i] += fmaxf(c[i] - dj, 0.f);
+    }
+}
+
+// one relation for this workgroup's rows.  out_c == nullptr: one network (d.adj_mode decides);  else actor (out) and critic
+// (out_c; c_valid: over the first kvalid[row] neighbours) from the same messages.
+template <int PT, bool QS, bool AS>
+__device__ __forceinline__ void msgw_fwd_rows(const MsgDims &d, const float *__restrict__ p, const float *__restrict__ q,
+                                              const float *__restrict__ e, const void *__restrict__ adj, const int32_t *__restrict__ kvalid,
+                                              const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ out,
+                                              float *__restrict__ out_c, bool c_valid) {
+    const int P = d.P, f = threadIdx.x;
+    float w[8];
+    for (int k = 0; k < 8; k++) w[k] = 0.f;
+    for (int k = 0; k < d.din; k++) w[k] = W[(size_t)f * d.din + k];
+    const float bias = b[f];
+    const int r0 = blockIdx.x * d.rpb, r1 = min(d.R, r0 + d.rpb);
+    if (r0 >= r1) return;
+    const bool use_kv = out_c != nullptr ? c_valid : d.adj_mode == MO_ADJ_VALID;
+    MsgRow m = msgw_load<QS, AS>(d, r0, p, q, e, adj, kvalid, use_kv);
+    for (int r = r0; r < r1; r++) {
+        const MsgRow nxt = msgw_load<QS, AS>(d, r + 1 < r1 ? r + 1 : r, p, q, e, adj, kvalid, use_kv);
+        const float4 *__restrict__ q4 = (const float4 *)(q + (size_t)(r / d.q_div) * d.q_rs);
+        float c[PT], acc[PT], inv[PT];
+        msgw_center<PT>(d, m, w, bias, c);
+        if (out_c != nullptr) {
+            float acv[PT];
+            msgw_ones_row<PT, QS>(m.kv, m, q4, w, c, acv);
+            const float inv_c = 1.f / fmaxf((float)m.kv, 1e-12f);
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+                if (i < P) out_c[((size_t)r * P + i) * d.o_is + f] = acv[i] * inv_c;
+            msgw_actor_row<PT, QS, AS>(d, r, m, q4, adj, w, c, acc, inv);
+        } else if (d.adj_mode == MO_ADJ_TENSOR || d.adj_mode == MO_ADJ_BITS) {
+            msgw_actor_row<PT, QS, AS>(d, r, m, q4, adj, w, c, acc, inv);
+        } else {
+            msgw_ones_row<PT, QS>(m.kv, m, q4, w, c, acc);
+            const float iv = 1.f / fmaxf((float)m.kv, 1e-12f);
+#pragma unroll
+            for (int i = 0; i < PT; i++) inv[i] = iv;
+        }
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+            if (i < P) out[((size_t)r * P + i) * d.o_is + f] = acc[i] * inv[i];
+        m = nxt;
+    }
+}
+
+template <int PT, bool QS, bool AS>
+__global__ void k_msgw_fwd(MsgDims d, const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
+                           const void *__restrict__ adj, const int32_t *__restrict__ kvalid, const float *__restrict__ W,
+                           const float *__restrict__ b, float *__restrict__ out) {
+    msgw_fwd_rows<PT, QS, AS>(d, p, q, e, adj, kvalid, W, b, out, nullptr, false);
+}
+
+// the three relations of DHGN.encoder (defender, evader: small neighbour sets; obstacle: large) of one network (out_c == nullptr)
+// or of actor and critic together, one launch.  (kvalid2 is handed to all three calls: a literal null there crashes this
+// hipcc's inliner; relations 0 and 1 never read it.)
+template <int PT, bool S01, bool AS2>
+__global__ void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDims d2, const float *__restrict__ p, const float *__restrict__ q0,
+                            const float *__restrict__ e0, const void *__restrict__ adj0, const float *__restrict__ W0,
+                            const float *__restrict__ b0, const float *__restrict__ q1, const void *__restrict__ adj1,
+                            const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ q2,
+                            const void *__restrict__ adj2, const int32_t *__restrict__ kvalid2, const float *__restrict__ W2,
+                            const float *__restrict__ b2, float *__restrict__ out, float *__restrict__ out_c, int c_valid) {
+    const int E = d0.E;
+    msgw_fwd_rows<PT, S01, S01>(d0, p, q0, e0, adj0, kvalid2, W0, b0, out, out_c, false);
+    msgw_fwd_rows<PT, S01, S01>(d1, p, q1, e0, adj1, kvalid2, W1, b1, out + E, out_c ? out_c + E : nullptr, false);
+    msgw_fwd_rows<PT, false, AS2>(d2, p, q2, e0, adj2, kvalid2, W2, b2, out + 2 * E, out_c ? out_c + 2 * E : nullptr, c_valid != 0);
+}
+
+// backward: per-thread partial sums over the workgroup's rows -> partials [gridDim.x][din + 1][E] (reduced by
+// k_msg_agg_bwd_reduce).  dW[:, k<4] = sum_i G_i p_i[k] - sum_j H_j q_j[k] with G_i = sum_j g_ij, H_j = sum_i g_ij,
+// g_ij = [z_ij > 0] abar_ij gout_i ; dW[:, 4+k] = sum_i G_i (p_i - e)[k] ; db = sum_i G_i.  For MO_ADJ_BITS the
+// neighbour-coordinate term is summed edge by edge instead of column by column (fp32 reassociation only).
+template <int PT, bool QS, bool AS>
+__global__ void k_msgw_bwd(MsgDims d, const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
+                           const void *__restrict__ adj, const int32_t *__restrict__ kvalid, const float *__restrict__ W,
+                           const float *__restrict__ b, const float *__restrict__ gout, float *__restrict__ partials) {
+    const int P = d.P, K = d.K, f = threadIdx.x;
+    float w[8], gw[8];
+    for (int k = 0; k < 8; k++) { w[k] = 0.f; gw[k] = 0.f; }
+    for (int k = 0; k < d.din; k++) w[k] = W[(size_t)f * d.din + k];
+    const float bias = b[f];
+    float gb = 0.f;
+    const int r0 = blockIdx.x * d.rpb, r1 = min(d.R, r0 + d.rpb);
+    const bool use_kv = d.adj_mode == MO_ADJ_VALID;
+    MsgRow m = msgw_load<QS, AS>(d, r0 < r1 ? r0 : 0, p, q, e, adj, kvalid, use_kv);
+    float go[PT];
+#pragma unroll
+    for (int i = 0; i < PT; i++) go[i] = (i < P && r0 < r1) ? gout[((size_t)r0 * P + i) * d.o_is + f] : 0.f;
+    for (int r = r0; r < r1; r++) {
+        const int rn = r + 1 < r1 ? r + 1 : r;
+        const MsgRow nxt = msgw_load<QS, AS>(d, rn, p, q, e, adj, kvalid, use_kv);
+        float gon[PT];
+#pragma unroll
+        for (int i = 0; i < PT; i++) gon[i] = i < P ? gout[((size_t)rn * P + i) * d.o_is + f] : 0.f;
+        const float4 *__restrict__ q4 = (const float4 *)(q + (size_t)(r / d.q_div) * d.q_rs);
+        float c[PT], G[PT];
+        msgw_center<PT>(d, m, w, bias, c);
+#pragma unroll
+        for (int i = 0; i < PT; i++) G[i] = 0.f;
         float hq0 = 0.f, hq1 = 0.f, hq2 = 0.f, hq3 = 0.f;
-        if (a.adj_mode == MO_ADJ_TENSOR || a.adj_mode == MO_ADJ_BITS) {
-            const bool bits = a.adj_mode == MO_ADJ_BITS;  // 0/1 adjacency: the set entries are exactly 1
+        if (d.adj_mode == MO_ADJ_BITS) {
+            const uint32_t *__restrict__ bw = (const uint32_t *)adj + (size_t)r * d.adj_rs;
+            const int nw = (K + 31) >> 5, RWK = MO_ADJ_ROW_WORDS(K);
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+                if (i < P) {
+                    int cnt = 0;
+                    for (int wd = 0; wd < nw; wd++) {
+                        uint32_t bits = msgw_word<AS>(m, bw, i * RWK + wd);
+                        if (wd == (K >> 5)) bits &= (1u << (K & 31)) - 1u;
+                        cnt += __popc(bits);
+                    }
+                    const float gi = go[i] * (1.f / fmaxf((float)cnt, 1e-12f));
+                    for (int wd = 0; wd < nw; wd++) {
+                        uint32_t bits = msgw_word<AS>(m, bw, i * RWK + wd);
+                        if (wd == (K >> 5)) bits &= (1u << (K & 31)) - 1u;
+                        while (bits) {
+                            const int j = (wd << 5) + __builtin_ctz(bits);
+                            bits &= bits - 1u;
+                            const float4 qv = msgw_q<QS>(m, q4, j);
+                            const float g = (c[i] - msg_dot4(w, qv) > 0.f) ? gi : 0.f;
+                            G[i] += g;
+                            hq0 = __builtin_fmaf(g, qv.x, hq0); hq1 = __builtin_fmaf(g, qv.y, hq1); hq2 = __builtin_fmaf(g, qv.z, hq2); hq3 = __builtin_fmaf(g, qv.w, hq3);
+                        }
+                    }
+                }
+        } else if (d.adj_mode == MO_ADJ_TENSOR && AS) {
+            const MsgMask k = msgw_mask(m, P, K);
+            float gi[PT];
+#pragma unroll
+            for (int i = 0; i < PT; i++) gi[i] = i < P ? go[i] * (1.f / fmaxf(msgw_row_norm(m, k, i, K), 1e-12f)) : 0.f;
             for (int j = 0; j < K; j++) {
-                const unsigned int m = l.col[j];
-                if (m == 0u) continue;
-                const float4 qv = ((const float4 *)l.q)[j];
-                const float d = msg_dot4(w, qv);
+                const uint64_t cm = (k.nz >> j) & k.col;
+                if (cm == 0ull) continue;
+                const float4 qv = msgw_q<QS>(m, q4, j);
+                const float dj = msg_dot4(w, qv);
                 float hj = 0.f;
 #pragma unroll
                 for (int i = 0; i < PT; i++)
-                    if (m & (1u << i)) {
-                        const float g = (c[i] - d > 0.f) ? gi[i] * (bits ? 1.f : l.adj[i * K + j]) : 0.f;
+                    if (i < P && ((cm >> (i * K)) & 1ull)) {
+                        const float aij = k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, i * K + j));
+                        const float g = (c[i] - dj > 0.f) ? gi[i] * aij : 0.f;
                         G[i] += g;
                         hj += g;
                     }
                 hq0 = __builtin_fmaf(hj, qv.x, hq0); hq1 = __builtin_fmaf(hj, qv.y, hq1); hq2 = __builtin_fmaf(hj, qv.z, hq2); hq3 = __builtin_fmaf(hj, qv.w, hq3);
             }
+        } else if (d.adj_mode == MO_ADJ_TENSOR) {
+            const float *__restrict__ ar = (const float *)adj + (size_t)r * d.adj_rs;
+            float gi[PT];
+#pragma unroll
+            for (int i = 0; i < PT; i++) {
+                gi[i] = 0.f;
+                if (i < P) {
+                    float s = 0.f;
+                    for (int j = 0; j < K; j++) s += fabsf(ar[i * K + j]);
+                    gi[i] = go[i] * (1.f / fmaxf(s, 1e-12f));
+                }
+            }
+            for (int j = 0; j < K; j++) {
+                bool any = false;
+                for (int i = 0; i < P; i++) any |= ar[i * K + j] != 0.f;
+                if (!any) continue;
+                const float4 qv = msgw_q<QS>(m, q4, j);
+                const float dj = msg_dot4(w, qv);
+                float hj = 0.f;
+#pragma unroll
+                for (int i = 0; i < PT; i++)
+                    if (i < P) {
+                        const float aij = ar[i * K + j];
+                        if (aij != 0.f) {
+                            const float g = (c[i] - dj > 0.f) ? gi[i] * aij : 0.f;
+                            G[i] += g;
+                            hj += g;
+                        }
+                    }
+                hq0 = __builtin_fmaf(hj, qv.x, hq0); hq1 = __builtin_fmaf(hj, qv.y, hq1); hq2 = __builtin_fmaf(hj, qv.z, hq2); hq3 = __builtin_fmaf(hj, qv.w, hq3);
+            }
         } else {
+            const int kv = m.kv;
+            const float iv = 1.f / fmaxf((float)kv, 1e-12f);
+            float gi[PT];
+#pragma unroll
+            for (int i = 0; i < PT; i++) gi[i] = go[i] * iv;
             for (int j = 0; j < kv; j++) {
-                const float4 qv = ((const float4 *)l.q)[j];
-                const float d = msg_dot4(w, qv);
+                const float4 qv = msgw_q<QS>(m, q4, j);
+                const float dj = msg_dot4(w, qv);
                 float hj = 0.f;
 #pragma unroll
                 for (int i = 0; i < PT; i++) {
-                    const float g = (c[i] - d > 0.f) ? gi[i] : 0.f;
+                    const float g = (c[i] - dj > 0.f) ? gi[i] : 0.f;
                     G[i] += g;
                     hj += g;
                 }
                 hq0 = __builtin_fmaf(hj, qv.x, hq0); hq1 = __builtin_fmaf(hj, qv.y, hq1); hq2 = __builtin_fmaf(hj, qv.z, hq2); hq3 = __builtin_fmaf(hj, qv.w, hq3);
             }
         }
+        const float e0 = rl_f(m.ve, 0), e1 = rl_f(m.ve, 1), e2 = rl_f(m.ve, 2), e3 = rl_f(m.ve, 3);
 #pragma unroll
         for (int i = 0; i < PT; i++)
             if (i < P) {
+                const float p0 = rl_f(m.vp, 4 * i), p1 = rl_f(m.vp, 4 * i + 1), p2 = rl_f(m.vp, 4 * i + 2), p3 = rl_f(m.vp, 4 * i + 3);
                 gb += G[i];
-                gw[0] += G[i] * l.p[i * 4]; gw[1] += G[i] * l.p[i * 4 + 1]; gw[2] += G[i] * l.p[i * 4 + 2]; gw[3] += G[i] * l.p[i * 4 + 3];
-                if (a.din == 8) {
-                    gw[4] += G[i] * l.pe[i * 4]; gw[5] += G[i] * l.pe[i * 4 + 1]; gw[6] += G[i] * l.pe[i * 4 + 2]; gw[7] += G[i] * l.pe[i * 4 + 3];
-                }
+                gw[0] += G[i] * p0; gw[1] += G[i] * p1; gw[2] += G[i] * p2; gw[3] += G[i] * p3;
+                if (d.din == 8) { gw[4] += G[i] * (p0 - e0); gw[5] += G[i] * (p1 - e1); gw[6] += G[i] * (p2 - e2); gw[7] += G[i] * (p3 - e3); }
             }
         gw[0] -= hq0; gw[1] -= hq1; gw[2] -= hq2; gw[3] -= hq3;
-        __syncthreads();
+        m = nxt;
+#pragma unroll
+        for (int i = 0; i < PT; i++) go[i] = gon[i];
     }
-    float *dst = partials + (size_t)blockIdx.x * (a.din + 1) * E;
-    for (int k = 0; k < a.din; k++) dst[k * E + f] = gw[k];
-    dst[a.din * E + f] = gb;
+    float *dst = partials + (size_t)blockIdx.x * (d.din + 1) * d.E;
+    for (int k = 0; k < d.din; k++) dst[k * d.E + f] = gw[k];
+    dst[d.din * d.E + f] = gb;
 }
 
 // one workgroup per output element group: 64 lanes split the partial blocks, then a wave reduction (deterministic order)
@@ -993,19 +1114,32 @@ __global__ void k_gru_bias_reduce(int nblk, const float *partials, float *db_ih,
     }
 }
 
-size_t msg_lds_bytes(int P, int K) { return sizeof(float) * (size_t)(K * 4 + msg_adj_floats(P, K) + P * 4 + P * 4 + MAX_P + K + 4); }
-
 int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, const void *adj, const void *kvalid, const void *e) {
     if (R < 0 || P < 1 || P > MAX_P || K < 1 || E < 64 || E > 256 || (E & 63) || (din != 4 && din != 8) || q_div < 1) return MO_ERR_BAD_ARG;
     if ((adj_mode == MO_ADJ_TENSOR || adj_mode == MO_ADJ_BITS) && !adj) return MO_ERR_BAD_ARG;
     if (adj_mode == MO_ADJ_VALID && !kvalid) return MO_ERR_BAD_ARG;
     if (adj_mode < 0 || adj_mode > 3) return MO_ERR_BAD_ARG;
     if (din == 8 && !e) return MO_ERR_BAD_ARG;
-    if (msg_lds_bytes(P, K) > 64 * 1024) return MO_ERR_BAD_ARG;
     return 0;
 }
 
-constexpr int BWD_BLOCKS = 1024;
+constexpr int BWD_BLOCKS = 2048, FWD_BLOCKS = 4096;
+
+bool msg_q_small(int K) { return 4 * K <= 64; }
+bool msg_adj_small(int P, int K, int adj_mode) {
+    if (adj_mode == MO_ADJ_TENSOR) return P * K <= 64;
+    if (adj_mode == MO_ADJ_BITS) return P * MO_ADJ_ROW_WORDS(K) <= 128;
+    return true;
+}
+
+MsgDims msg_dims(int R, int P, int K, int E, int din, int q_div, int adj_mode, int64_t p_rs, int64_t q_rs, int64_t e_rs, int64_t adj_rs,
+                 int64_t o_is, int max_blocks, int *grid) {
+    const int g0 = R < max_blocks ? (R > 0 ? R : 1) : max_blocks;
+    const int rpb = (R + g0 - 1) / g0;
+    *grid = (R + rpb - 1) / (rpb > 0 ? rpb : 1);
+    if (*grid < 1) *grid = 1;
+    return MsgDims{R, P, K, E, din, q_div, adj_mode, rpb > 0 ? rpb : 1, p_rs, q_rs, e_rs, adj_rs, o_is};
+}
 
 // ---- PPO policy / value loss of one mini-batch, forward and gradients in one pass (DHGN/mappo_parallel.py:692-706) -------
 // Element-wise fp32 arithmetic in torch's op order (so the values match the op-by-op graph), masked sums in f64 through
@@ -1248,6 +1382,32 @@ int wgrad_split(int M, int N, int *am, int *bn) {  // tile shape and number of K
     return S < 1 ? 1 : S;
 }
 
+int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int64_t p_rs, const int32_t *kvalid2, float *out, float *out_c,
+                 int c_valid, int64_t out_stride, void *stream, bool pair) {
+    MsgDims d[3];
+    int grid = 1;
+    for (int r = 0; r < 3; r++) {
+        const mo_msg_rel &m = rel[r];
+        int rc = check_msg(R, P, m.K, E, m.din, m.q_div, m.adj_mode, m.adj, m.kvalid, m.e);
+        if (rc) return rc;
+        if ((m.q_rs & 3) || out_stride < 3 * E) return MO_ERR_BAD_ARG;
+        if (r < 2 && m.adj_mode == MO_ADJ_VALID) return MO_ERR_BAD_ARG;  // only the obstacle relation carries kvalid
+        d[r] = msg_dims(R, P, m.K, E, m.din, m.q_div, m.adj_mode, p_rs, m.q_rs, m.e_rs, m.adj_rs, out_stride, FWD_BLOCKS, &grid);
+    }
+    const bool s01 = msg_q_small(rel[0].K) && msg_q_small(rel[1].K) && msg_adj_small(P, rel[0].K, rel[0].adj_mode) &&
+                     msg_adj_small(P, rel[1].K, rel[1].adj_mode);
+    const bool as2 = msg_adj_small(P, rel[2].K, rel[2].adj_mode);
+#define MSGW3_LAUNCH(PT, S01, AS2)                                                                                                          \
+    hipLaunchKernelGGL((k_msgw3_fwd<PT, S01, AS2>), dim3(grid), dim3(E), 0, (hipStream_t)stream, d[0], d[1], d[2], p, rel[0].q, rel[0].e,      \
+                       rel[0].adj, rel[0].W, rel[0].b, rel[1].q, rel[1].adj, rel[1].W, rel[1].b, rel[2].q, rel[2].adj, kvalid2, rel[2].W,    \
+                       rel[2].b, out, out_c, c_valid)
+#define MSGW3_PT(PT) { if (s01 && as2) MSGW3_LAUNCH(PT, true, true); else if (s01) MSGW3_LAUNCH(PT, true, false); else if (as2) MSGW3_LAUNCH(PT, false, true); else MSGW3_LAUNCH(PT, false, false); }
+    if (P <= 8) MSGW3_PT(8) else MSGW3_PT(16)
+#undef MSGW3_PT
+#undef MSGW3_LAUNCH
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1259,11 +1419,14 @@ int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
     if (rc) return rc;
     if (R == 0) return 0;
     if ((q_rs & 3) || out_stride < E) return MO_ERR_BAD_ARG;
-    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, (const float *)adj, p_rs, q_rs, e_rs, adj_rs, out_stride, kvalid, W, b};
-    const int grid = R < 8192 ? R : 8192;
-    if (P <= 4) hipLaunchKernelGGL(k_msg_agg_fwd<4>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
-    else if (P <= 8) hipLaunchKernelGGL(k_msg_agg_fwd<8>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
-    else hipLaunchKernelGGL(k_msg_agg_fwd<16>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, out);
+    int grid;
+    const MsgDims d = msg_dims(R, P, K, E, din, q_div, adj_mode, p_rs, q_rs, e_rs, adj_rs, out_stride, FWD_BLOCKS, &grid);
+    const bool qs = msg_q_small(K), as = msg_adj_small(P, K, adj_mode);
+#define MSGW_FWD(PT, QS, AS) hipLaunchKernelGGL((k_msgw_fwd<PT, QS, AS>), dim3(grid), dim3(E), 0, (hipStream_t)stream, d, p, q, e, adj, kvalid, W, b, out)
+#define MSGW_FWD_PT(PT) { if (qs && as) MSGW_FWD(PT, true, true); else if (qs) MSGW_FWD(PT, true, false); else if (as) MSGW_FWD(PT, false, true); else MSGW_FWD(PT, false, false); }
+    if (P <= 8) MSGW_FWD_PT(8) else MSGW_FWD_PT(16)
+#undef MSGW_FWD_PT
+#undef MSGW_FWD
     return (int)hipGetLastError();
 }
 
@@ -1271,47 +1434,16 @@ int dhgn_msg_agg3_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, co
                       void *stream) {
     if (!rel || !p || !out || R < 0) return MO_ERR_BAD_ARG;
     if (R == 0) return 0;
-    MsgArgs a[3];
-    size_t lds = 0;
-    for (int r = 0; r < 3; r++) {
-        const mo_msg_rel &m = rel[r];
-        int rc = check_msg(R, P, m.K, E, m.din, m.q_div, m.adj_mode, m.adj, m.kvalid, m.e);
-        if (rc) return rc;
-        if ((m.q_rs & 3) || out_stride < 3 * E) return MO_ERR_BAD_ARG;
-        a[r] = MsgArgs{R, P, m.K, E, m.din, m.q_div, m.adj_mode, p, m.q, m.e, (const float *)m.adj, p_rs, m.q_rs, m.e_rs, m.adj_rs, out_stride, m.kvalid, m.W, m.b};
-        const size_t l = msg_lds_bytes(P, m.K);
-        lds = l > lds ? l : lds;
-    }
-    const int grid = R < 8192 ? R : 8192;
-    if (P <= 4) hipLaunchKernelGGL(k_msg_agg3_fwd<4>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], out, out + E, out + 2 * E);
-    else if (P <= 8) hipLaunchKernelGGL(k_msg_agg3_fwd<8>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], out, out + E, out + 2 * E);
-    else hipLaunchKernelGGL(k_msg_agg3_fwd<16>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], out, out + E, out + 2 * E);
-    return (int)hipGetLastError();
+    return launch_msgw3(rel, R, P, E, p, p_rs, rel[2].kvalid, out, nullptr, 0, out_stride, stream, false);
 }
 
 int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_rs, const int32_t *o_kvalid,
                            float *out_actor, float *out_critic, int64_t out_stride, void *stream) {
     if (!rel || !p || !out_actor || !out_critic || R < 0) return MO_ERR_BAD_ARG;
     if (R == 0) return 0;
-    MsgArgs a[3];
-    size_t lds = 0;
-    for (int r = 0; r < 3; r++) {
-        const mo_msg_rel &m = rel[r];
-        if (m.adj_mode != MO_ADJ_TENSOR && m.adj_mode != MO_ADJ_BITS) return MO_ERR_BAD_ARG;  // the actor's adjacency
-        int rc = check_msg(R, P, m.K, E, m.din, m.q_div, m.adj_mode, m.adj, nullptr, m.e);
-        if (rc) return rc;
-        if ((m.q_rs & 3) || out_stride < 3 * E) return MO_ERR_BAD_ARG;
-        a[r] = MsgArgs{R, P, m.K, E, m.din, m.q_div, m.adj_mode, p, m.q, m.e, (const float *)m.adj, p_rs, m.q_rs, m.e_rs, m.adj_rs, out_stride,
-                       r == 2 ? o_kvalid : nullptr, m.W, m.b};
-        const size_t l = msg_lds_bytes(P, m.K);
-        lds = l > lds ? l : lds;
-    }
-    const int grid = R < 8192 ? R : 8192;
-    const bool cv = o_kvalid != nullptr;
-    if (P <= 4) hipLaunchKernelGGL(k_msg_agg3_pair_fwd<4>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], cv, out_actor, out_critic);
-    else if (P <= 8) hipLaunchKernelGGL(k_msg_agg3_pair_fwd<8>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], cv, out_actor, out_critic);
-    else hipLaunchKernelGGL(k_msg_agg3_pair_fwd<16>, dim3(grid), dim3(E), lds, (hipStream_t)stream, a[0], a[1], a[2], cv, out_actor, out_critic);
-    return (int)hipGetLastError();
+    for (int r = 0; r < 3; r++)
+        if (rel[r].adj_mode != MO_ADJ_TENSOR && rel[r].adj_mode != MO_ADJ_BITS) return MO_ERR_BAD_ARG;  // the actor's adjacency
+    return launch_msgw3(rel, R, P, E, p, p_rs, o_kvalid, out_actor, out_critic, o_kvalid != nullptr, out_stride, stream, true);
 }
 
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD_BLOCKS * (din + 1) * E * sizeof(float); }
@@ -1324,11 +1456,15 @@ int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
     if (rc) return rc;
     if (!workspace || !gout || !dW || !db) return MO_ERR_BAD_ARG;
     if ((q_rs & 3) || gout_stride < E) return MO_ERR_BAD_ARG;
-    MsgArgs a{R, P, K, E, din, q_div, adj_mode, p, q, e, (const float *)adj, p_rs, q_rs, e_rs, adj_rs, gout_stride, kvalid, W, b};
-    const int grid = R < BWD_BLOCKS ? (R > 0 ? R : 1) : BWD_BLOCKS;
-    if (P <= 4) hipLaunchKernelGGL(k_msg_agg_bwd<4>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);
-    else if (P <= 8) hipLaunchKernelGGL(k_msg_agg_bwd<8>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);
-    else hipLaunchKernelGGL(k_msg_agg_bwd<16>, dim3(grid), dim3(E), msg_lds_bytes(P, K), (hipStream_t)stream, a, gout, (float *)workspace);
+    int grid;
+    const MsgDims d = msg_dims(R, P, K, E, din, q_div, adj_mode, p_rs, q_rs, e_rs, adj_rs, gout_stride, BWD_BLOCKS, &grid);
+    const bool qs = msg_q_small(K), as = msg_adj_small(P, K, adj_mode);
+#define MSGW_BWD(PT, QS, AS) \
+    hipLaunchKernelGGL((k_msgw_bwd<PT, QS, AS>), dim3(grid), dim3(E), 0, (hipStream_t)stream, d, p, q, e, adj, kvalid, W, b, gout, (float *)workspace)
+#define MSGW_BWD_PT(PT) { if (qs && as) MSGW_BWD(PT, true, true); else if (qs) MSGW_BWD(PT, true, false); else if (as) MSGW_BWD(PT, false, true); else MSGW_BWD(PT, false, false); }
+    if (P <= 8) MSGW_BWD_PT(8) else MSGW_BWD_PT(16)
+#undef MSGW_BWD_PT
+#undef MSGW_BWD
     const int tot = (din + 1) * E;
     hipLaunchKernelGGL(k_msg_agg_bwd_reduce, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, grid, E, din,
                        (const float *)workspace, dW, db);

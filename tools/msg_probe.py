@@ -1,0 +1,72 @@
+"""Per-relation timing of the message/aggregate kernels on REAL rollout data (realistic adjacency sparsity and obstacle counts):
+the update's shapes (one mini-batch, q_div = T) forward and backward, and the rollout's per-tick shapes.
+  python3 tools/msg_probe.py [cfg2]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from distributed_multi_agent_reinforcement_learning_amd.config import baseline_config
+from distributed_multi_agent_reinforcement_learning_amd.trainer import Trainer
+from distributed_multi_agent_reinforcement_learning_amd import ops
+
+cfg = baseline_config(sys.argv[1] if len(sys.argv) > 1 else "cfg2")
+tr = Trainer(cfg)
+ag, env = tr.agent, tr.env
+_, rb, _ = ag.explore_env(env, 1)
+batch = rb.get_training_data(ag.device) if hasattr(rb, "get_training_data") else rb.buffer
+N, T, P = batch["r"].shape
+mb = tr.mini_batch_size
+R = mb * T
+E = ag.embedding_dim
+enc = ag.actor.shared_net
+M = enc.MSG_layers
+p = batch["p_state"][:mb].reshape(R, P, -1)
+e = batch["e_state"][:mb].reshape(R, 1, -1)
+o = rb.o_static[:mb]
+adj_p = batch["p_adj"][:mb].reshape(R, P, P)
+adj_e = batch["e_adj"][:mb].reshape(R, P, 1)
+adj_o = batch["o_adj_bits"][:mb].reshape(R, P, -1)
+kv = rb.o_kvalid[:mb]
+print(f"R={R} P={P} K={o.shape[1]} n_obs mean {kv.float().mean().item():.1f} max {kv.max().item()}; o_adj density "
+      f"{ops.unpack_adj_bits(adj_o[:3000], o.shape[1]).mean().item():.4f}; seen columns/row "
+      f"{(ops.unpack_adj_bits(adj_o[:3000], o.shape[1]).amax(1) > 0).float().sum(-1).mean().item():.1f}")
+
+
+def timeit(fn, n=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+gout = torch.randn(R, P, E, device=p.device)
+rels = (("defender", p, e.reshape(R, 4), adj_p, M[0], 1), ("evader", e, None, adj_e, M[1], 1), ("obstacle", o, None, adj_o, M[2], T))
+for name, q, ee, adj, lin, qd in rels:
+    W, b = lin.weight.detach(), lin.bias.detach()
+    for mode_name in ("actor", "critic-dense"):
+        if mode_name == "actor":
+            mode = ops.ADJ_BITS if adj.dtype == torch.int32 else ops.ADJ_TENSOR
+        else:
+            mode = ops.ADJ_ONES
+        Wg, bg = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        with torch.no_grad():
+            t_f = timeit(lambda: ops.msg_agg(p, q, ee, adj, W, b, mode, None, qd))
+        with torch.enable_grad():
+            out = ops.msg_agg(p, q, ee, adj, Wg, bg, mode, None, qd)
+        t_b = timeit(lambda: torch.autograd.grad(out, (Wg, bg), gout, retain_graph=True))
+        print(f"update {name:9s} {mode_name:12s} fwd {t_f:8.1f} us  bwd {t_b:8.1f} us")
+
+st = ag._rstate
+ob = st._obs()
+Rr = ob["p_state"].shape[0]
+wb = (M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias)
+with torch.no_grad():
+    t_pair = timeit(lambda: ops.msg_agg3_pair(ob["p_state"], ob["e_state"], ob["o_state"], ob["p_adj"], ob["e_adj"], ob["o_adj_bits"], *wb, ob["o_kvalid"], 1), 20)
+    t_a = timeit(lambda: ops.msg_agg3(ob["p_state"], ob["e_state"], ob["o_state"], ob["p_adj"], ob["e_adj"], ob["o_adj_bits"], *wb, False, None, 1), 20)
+    t_c = timeit(lambda: ops.msg_agg3(ob["p_state"], ob["e_state"], ob["o_state"], ob["p_adj"], ob["e_adj"], ob["o_adj_bits"], *wb, True, ob["o_kvalid"], 1), 20)
+print(f"rollout tick R={Rr}: pair {t_pair:.1f} us, actor {t_a:.1f} us, critic {t_c:.1f} us")
