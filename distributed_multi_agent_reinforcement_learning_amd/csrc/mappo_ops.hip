@@ -1265,13 +1265,17 @@ __device__ __forceinline__ void wgrad_load(WgradRegs<AM, BN, U> &r, const float 
     }
 }
 
-template <int AM, int BN, int U>
-__device__ __forceinline__ void wgrad_mma(const WgradRegs<AM, BN, U> &r, v4f (&acc)[AM][4][BN][4]) {
+template <int AM, int BN, int U, bool CS>
+__device__ __forceinline__ void wgrad_mma(const WgradRegs<AM, BN, U> &r, v4f (&acc)[AM][4][BN][4], float (&cs)[AM][4]) {
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
         for (int a = 0; a < AM; a++) {
             const float av[4] = {r.a[u][a].x, r.a[u][a].y, r.a[u][a].z, r.a[u][a].w};
+            if (CS) {  // column sums of A (the bias gradient) ride in VALU slots beside the MFMAs
+#pragma unroll
+                for (int t = 0; t < 4; t++) cs[a][t] += av[t];
+            }
 #pragma unroll
             for (int b = 0; b < BN; b++) {
                 const float bv[4] = {r.b[u][b].x, r.b[u][b].y, r.b[u][b].z, r.b[u][b].w};
@@ -1283,9 +1287,9 @@ __device__ __forceinline__ void wgrad_mma(const WgradRegs<AM, BN, U> &r, v4f (&a
         }
 }
 
-template <int AM, int BN>
+template <int AM, int BN, bool CS>
 __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int64_t K,
-                                               int M, int N, float *__restrict__ part) {
+                                               int M, int N, float *__restrict__ part, float *__restrict__ part_cs) {
     constexpr int U = 4;  // k-steps per pipeline stage (measured: 2 exposes load latency, 6+ lengthens the unpipelined ends)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 15, kk = lane >> 4;
@@ -1304,6 +1308,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
             for (int b = 0; b < BN; b++)
 #pragma unroll
                 for (int v = 0; v < 4; v++) acc[a][t][b][v] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float cs[AM][4];
+#pragma unroll
+    for (int a = 0; a < AM; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) cs[a][t] = 0.f;
     // Straight-line pipeline (no branch around a load: the s_waitcnt counts stay exact): pairs of U-step chunks, the
     // loads of the chunk after next are issued before the MFMAs of the current one; past the end the last chunk is
     // re-loaded (discarded) instead of branching.
@@ -1313,14 +1322,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
     for (int64_t c = 0; c < pairs; c++) {
         wgrad_load<AM, BN, U>(r1, pa + U * lda4, pb + U * ldb4, lda4, ldb4);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler would sink it to its use)
-        wgrad_mma<AM, BN, U>(r0, acc);
+        wgrad_mma<AM, BN, U, CS>(r0, acc, cs);
         __builtin_amdgcn_sched_barrier(0);
         const int64_t adv = (c + 1 < pairs) ? 2 * U : U;
         pa += adv * lda4;
         pb += adv * ldb4;
         wgrad_load<AM, BN, U>(r0, pa, pb, lda4, ldb4);
         __builtin_amdgcn_sched_barrier(0);
-        wgrad_mma<AM, BN, U>(r1, acc);
+        wgrad_mma<AM, BN, U, CS>(r1, acc, cs);
         __builtin_amdgcn_sched_barrier(0);
     }
     {   // the n_s % 2U left-over steps, then (last workgroup) the K % 4 tail rows, zero-filled
@@ -1329,7 +1338,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
         WgradRegs<AM, BN, 1> r;
         for (int64_t s = s_beg + pairs * 2 * U; s < s_end; s++) {
             wgrad_load<AM, BN, 1>(r, pa, pb, lda4, ldb4);
-            wgrad_mma<AM, BN, 1>(r, acc);
+            wgrad_mma<AM, BN, 1, CS>(r, acc, cs);
             pa += lda4;
             pb += ldb4;
         }
@@ -1339,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
             for (int a = 0; a < AM; a++) r.a[0][a] = live ? *(const float4 *)(pa + a * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int b = 0; b < BN; b++) r.b[0][b] = live ? *(const float4 *)(pb + b * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wgrad_mma<AM, BN, 1>(r, acc);
+            wgrad_mma<AM, BN, 1, CS>(r, acc, cs);
         }
     }
     // D tile (a,t | b,v): lane l, register q holds row 4 (l / 16) + q, column l % 16 of the tile, i.e. output row
@@ -1355,12 +1364,38 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
                 for (int b = 0; b < BN; b++)
                     *(float4 *)(po + (size_t)(64 * a + 4 * q + t) * N + 64 * b) =
                         make_float4(acc[a][t][b][0][q], acc[a][t][b][1][q], acc[a][t][b][2][q], acc[a][t][b][3][q]);
+    if (CS) {  // this lane summed columns m0 + 64 a + 4 i + t over its rows (k-step row kk): fold the four kk groups, one store
+#pragma unroll
+        for (int a = 0; a < AM; a++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                cs[a][t] += __shfl_xor(cs[a][t], 16);
+                cs[a][t] += __shfl_xor(cs[a][t], 32);
+            }
+        if (blockIdx.z == 0 && (wave & 1) == 0 && kk == 0) {
+#pragma unroll
+            for (int a = 0; a < AM; a++)
+                *(float4 *)(part_cs + (size_t)blockIdx.x * M + m0 + 64 * a + 4 * i) = make_float4(cs[a][0], cs[a][1], cs[a][2], cs[a][3]);
+        }
+    }
 }
 
 // C[m][n] = (accumulate ? C[m][n] : 0) + sum_x part[x][m][n], x ascending: the same order every run
-__global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float *__restrict__ part, float *__restrict__ C, int accumulate) {
+// (threads MN .. MN + M - 1: the column sums of A, colsum[m] = sum_x part_cs[x][m], when requested)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float *__restrict__ part, float *__restrict__ C, int accumulate,
+                                                      int M, const float *__restrict__ part_cs, float *__restrict__ colsum) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= MN) return;
+    if (idx >= MN) {
+        const int m = idx - MN;
+        if (colsum != nullptr && m < M) {
+            float c0 = 0.f, c1 = 0.f;
+            int x = 0;
+            for (; x + 2 <= S; x += 2) { c0 += part_cs[(size_t)x * M + m]; c1 += part_cs[(size_t)(x + 1) * M + m]; }
+            if (x < S) c0 += part_cs[(size_t)x * M + m];
+            colsum[m] = c0 + c1;
+        }
+        return;
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int x = 0;
     for (; x + 4 <= S; x += 4) {
@@ -1372,6 +1407,79 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float
     for (; x < S; x++) s0 += part[(size_t)x * MN + idx];
     const float s = (s0 + s1) + (s2 + s3);
     C[idx] = accumulate ? C[idx] + s : s;
+}
+
+// ---- skinny weight gradient: C [NS][F] = S^T X over R rows, S [R][NS] with NS <= 16 -----------------------------------------
+// The Linear layers with a handful of inputs or outputs (the K = 4 position part of DHGN's semantic layer, the action and value
+// heads): the library runs these 128 x {1, 4, 9} x 492 000 reductions at 0.2-0.3 ms; they are one streaming pass over X
+// (252 MB): lane = column of X, the row of S comes through uniform addresses, NS multiply-adds per element.  Optional column
+// sums of X and of S (the bias gradients) from the same pass.  Per-workgroup partials, then k_skinny_reduce (fixed order).
+constexpr int SK_MAX = 16, SK_BLOCKS = 2048, SK_U = 8;  // rows in flight per lane
+template <int NS>
+__global__ void k_wgrad_skinny(int64_t R, int F, const float *__restrict__ S, int64_t lds_, const float *__restrict__ X, int64_t ldx,
+                               float *__restrict__ part) {
+    const int f = threadIdx.x;
+    const int64_t rpb = (R + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
+    float acc[NS], cs[NS], cx = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; k++) { acc[k] = 0.f; cs[k] = 0.f; }
+    int64_t r = r0;
+    for (; r + SK_U <= r1; r += SK_U) {
+        float xv[SK_U];
+#pragma unroll
+        for (int u = 0; u < SK_U; u++) xv[u] = X[(r + u) * ldx + f];
+#pragma unroll
+        for (int u = 0; u < SK_U; u++) {
+            const float *__restrict__ sr = S + (r + u) * lds_;
+            cx += xv[u];
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const float sk = sr[k];
+                acc[k] = __builtin_fmaf(sk, xv[u], acc[k]);
+                cs[k] += sk;
+            }
+        }
+    }
+    for (; r < r1; r++) {
+        const float x0 = X[r * ldx + f];
+        const float *__restrict__ sr = S + r * lds_;
+        cx += x0;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const float sk = sr[k];
+            acc[k] = __builtin_fmaf(sk, x0, acc[k]);
+            cs[k] += sk;
+        }
+    }
+    // partials [block][NS + 1][F] then [block][NS] (column sums of S, identical in every lane)
+    float *dst = part + (size_t)blockIdx.x * ((NS + 1) * F + NS);
+#pragma unroll
+    for (int k = 0; k < NS; k++) dst[k * F + f] = acc[k];
+    dst[NS * F + f] = cx;
+    if (f == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; k++) dst[(NS + 1) * F + k] = cs[k];
+    }
+}
+
+// one wave per output element: C[k][f] (or C[f][k] when transposed), colsum_x[f], colsum_s[k]; f64 accumulation, fixed order
+__global__ void k_skinny_reduce(int nblk, int NS, int F, const float *__restrict__ part, int transposed, float *__restrict__ C,
+                                float *__restrict__ colsum_x, float *__restrict__ colsum_s) {
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, per = (NS + 1) * F + NS;
+    if (idx >= per) return;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * per + idx];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane != 0) return;
+    if (idx < NS * F) {
+        const int k = idx / F, f = idx - k * F;
+        C[transposed ? (size_t)f * NS + k : (size_t)k * F + f] = (float)s;
+    } else if (idx < (NS + 1) * F) {
+        if (colsum_x) colsum_x[idx - NS * F] = (float)s;
+    } else if (colsum_s) {
+        colsum_s[idx - (NS + 1) * F] = (float)s;
+    }
 }
 
 int wgrad_split(int M, int N, int *am, int *bn) {  // tile shape and number of K-splits: one workgroup per CU
@@ -1612,22 +1720,57 @@ int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float 
 int64_t wgrad_tn_workspace(int32_t M, int32_t N) {
     if (M < 128 || N < 128 || (M & 127) || (N & 127)) return -1;
     int am, bn;
-    return (int64_t)wgrad_split(M, N, &am, &bn) * M * N * sizeof(float);
+    return (int64_t)wgrad_split(M, N, &am, &bn) * ((int64_t)M * N + M) * sizeof(float);
 }
 
 int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
              void *workspace, void *stream) {
+    return wgrad_tn_colsum(K, M, N, A, lda, B, ldb, C, accumulate, nullptr, workspace, stream);
+}
+
+int wgrad_tn_colsum(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
+                    float *colsum_a, void *workspace, void *stream) {
     if (K < 1 || M < 128 || N < 128 || (M & 127) || (N & 127) || M > 1024 || N > 1024 || !A || !B || !C || !workspace) return MO_ERR_BAD_ARG;
     if (lda < M || ldb < N || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return MO_ERR_BAD_ARG;
     int am, bn;
     const int S = wgrad_split(M, N, &am, &bn);
     const dim3 grid(S, M / (128 * am), N / (128 * bn));
     hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace, *part_cs = part + (size_t)S * M * N;
+#define WGRAD_LAUNCH(AM, BN, CS) hipLaunchKernelGGL((k_wgrad<AM, BN, CS>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part, part_cs)
+    if (colsum_a) {
+        if (am == 3) WGRAD_LAUNCH(3, 1, true);
+        else if (bn == 3) WGRAD_LAUNCH(1, 3, true);
+        else WGRAD_LAUNCH(1, 1, true);
+    } else {
+        if (am == 3) WGRAD_LAUNCH(3, 1, false);
+        else if (bn == 3) WGRAD_LAUNCH(1, 3, false);
+        else WGRAD_LAUNCH(1, 1, false);
+    }
+#undef WGRAD_LAUNCH
+    const int threads = M * N + (colsum_a ? M : 0);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((threads + 255) / 256), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate, (int)M,
+                       (const float *)part_cs, colsum_a);
+    return (int)hipGetLastError();
+}
+
+int64_t wgrad_skinny_workspace(int32_t NS, int32_t F) { return (int64_t)SK_BLOCKS * ((NS + 1) * F + NS) * sizeof(float); }
+
+int wgrad_skinny(int64_t R, int32_t NS, int32_t F, const float *S, int64_t lds, const float *X, int64_t ldx, int32_t transposed, float *C,
+                 float *colsum_x, float *colsum_s, void *workspace, void *stream) {
+    if (R < 1 || NS < 1 || NS > SK_MAX || F < 64 || F > 1024 || (F & 63) || !S || !X || !C || !workspace || lds < NS || ldx < F) return MO_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = R < SK_BLOCKS ? (int)R : SK_BLOCKS;
     float *part = (float *)workspace;
-    if (am == 3) hipLaunchKernelGGL((k_wgrad<3, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
-    else if (bn == 3) hipLaunchKernelGGL((k_wgrad<1, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
-    else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate);
+    switch (NS) {
+#define SK_CASE(n) case n: hipLaunchKernelGGL((k_wgrad_skinny<n>), dim3(grid), dim3(F), 0, st, R, (int)F, S, lds, X, ldx, part); break;
+        SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12)
+        SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
+#undef SK_CASE
+    }
+    const int per = (NS + 1) * F + NS;
+    hipLaunchKernelGGL(k_skinny_reduce, dim3((per + 3) / 4), dim3(256), 0, st, grid, (int)NS, (int)F, (const float *)part, (int)transposed, C, colsum_x,
+                       colsum_s);
     return (int)hipGetLastError();
 }
 

@@ -17,10 +17,18 @@ from torch.nn.utils.spectral_norm import SpectralNorm
 from . import ops
 
 
-def _ortho_linear(n_in, n_out):
+class HeadLinear(nn.Linear):
+    """nn.Linear (same parameters, initialisation and state_dict) for the action / value heads: a handful of outputs, so under
+    autograd the weight and bias gradients take the streaming kernel (ops.linear_skinny) instead of 128 x {1, 9} x rows GEMMs."""
+
+    def forward(self, x):
+        return ops.linear_skinny(x, self.weight, self.bias)
+
+
+def _ortho_linear(n_in, n_out, cls=nn.Linear):
     """reference preproc_layer without spectral norm (DHGN/mappo_parallel.py:19-31): default Linear init is drawn
     first (it consumes the generator), then weights are re-drawn orthogonal (gain 1) and the bias zeroed."""
-    layer = nn.Linear(n_in, n_out)
+    layer = cls(n_in, n_out)
     for name, param in layer.named_parameters():
         if "bias" in name:
             nn.init.constant_(param, 0)
@@ -29,9 +37,9 @@ def _ortho_linear(n_in, n_out):
     return layer
 
 
-def _make_linear(n_in, n_out, is_sn):
+def _make_linear(n_in, n_out, is_sn, cls=nn.Linear):
     # `preproc_layer(a, b) if is_sn else nn.Linear(a, b)` -- note is_sn is NOT forwarded
-    return _ortho_linear(n_in, n_out) if is_sn else nn.Linear(n_in, n_out)
+    return _ortho_linear(n_in, n_out, cls) if is_sn else cls(n_in, n_out)
 
 
 class DHGN(nn.Module):
@@ -81,7 +89,7 @@ class DHGN(nn.Module):
             torch.addmm(self.semantic_layer.bias, p2, Ws[:, :ind].t(), out=o2)
             h0 = o2.addmm_(e2, Ws[:, ind:].t())
         else:
-            h0 = ops.linear(e2, Ws[:, ind:], F.linear(p2, Ws[:, :ind], self.semantic_layer.bias), consume_addend=True)
+            h0 = ops.linear(e2, Ws[:, ind:], ops.linear_skinny(p2, Ws[:, :ind], self.semantic_layer.bias), consume_addend=True)
         return h0.reshape(R, P, E)
 
     # -- fixed-depth recursive aggregation over neighbours' historical embeddings (:204-233) --------------
@@ -203,7 +211,7 @@ class SharedActor(_Trunk):
         self.rnn_input_dim = rnn_input_dim
         self.rnn_hidden_dim = rnn_hidden_dim
         self.GRU = nn.GRU(rnn_input_dim, rnn_hidden_dim, num_layers)
-        self.Mean = _make_linear(rnn_hidden_dim, action_dim, is_sn)
+        self.Mean = _make_linear(rnn_hidden_dim, action_dim, is_sn, HeadLinear)
 
     def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, inplace_hidden=False, emb_out=None):
         """mode 0 (one step for R environments): returns prob (R,P,A), hidden, embedding (R,P,E)   (:422-425)
@@ -232,7 +240,7 @@ class SharedCritic(_Trunk):
         self.rnn_input_dim = rnn_input_dim
         self.rnn_hidden_dim = rnn_hidden_dim
         self.GRU = nn.GRU(rnn_input_dim, rnn_hidden_dim, num_layers)
-        head = _ortho_linear(rnn_hidden_dim, value_dim)
+        head = _ortho_linear(rnn_hidden_dim, value_dim, HeadLinear)
         self.Mean = spectral_norm(head) if is_sn else head  # the only spectrally normalised layer (:485)
 
     def forward(self, obs, hist, hidden_state=None, mode=0, batch=None, steps=None, rollout=False, inplace_hidden=False,

@@ -59,6 +59,10 @@ def load_library():
         L.wgrad_tn_workspace.argtypes = [i32, i32]
         L.wgrad_tn_workspace.restype = i64
         L.wgrad_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
+        L.wgrad_tn_colsum.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp, vp]
+        L.wgrad_skinny_workspace.argtypes = [i32, i32]
+        L.wgrad_skinny_workspace.restype = i64
+        L.wgrad_skinny.argtypes = [i64, i32, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp]
         L.rollout_record.argtypes = [i32, i32, vp, vp, vp, i32, vp]
         L.ppo_loss_workspace.restype = i64
         L.ppo_loss_fwd_bwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp]
@@ -401,14 +405,17 @@ def _wgrad_ok(a, b):
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
-def wgrad(a, b, out=None, accumulate=False):
+def wgrad(a, b, out=None, accumulate=False, colsum=False):
     """a^T b for a (K, M), b (K, N) row-major (rows may be strided): the weight gradient of a Linear / GRU projection over
     the K rows of a minibatch (the `grad_output.t() @ input` of autograd, DHGN/mappo_parallel.py:660-708).  Shapes the
-    split-K MFMA kernel covers (M, N multiples of 128) run in csrc/mappo_ops.hip k_wgrad, the rest in the BLAS library."""
+    split-K MFMA kernel covers (M, N multiples of 128) run in csrc/mappo_ops.hip k_wgrad, the rest in the BLAS library.
+    colsum: also return a.sum(0) (the bias gradient when a = grad_output), computed in the same pass over a."""
     if not _wgrad_ok(a, b):
         if out is None:
-            return torch.mm(a.t(), b)
-        return out.addmm_(a.t(), b) if accumulate else torch.mm(a.t(), b, out=out)
+            res = torch.mm(a.t(), b)
+        else:
+            res = out.addmm_(a.t(), b) if accumulate else torch.mm(a.t(), b, out=out)
+        return (res, a.sum(0)) if colsum else res
     L = load_library()
     M, N = a.shape[1], b.shape[1]
     if out is None:
@@ -416,9 +423,84 @@ def wgrad(a, b, out=None, accumulate=False):
         accumulate = False
     assert out.is_contiguous() and out.shape == (M, N)
     ws = torch.empty(L.wgrad_tn_workspace(M, N), dtype=torch.uint8, device=a.device)
+    if colsum:
+        cs = torch.empty(M, dtype=a.dtype, device=a.device)
+        _check(L.wgrad_tn_colsum(a.shape[0], M, N, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(bool(accumulate)), _ptr(cs), _ptr(ws),
+                                 _stream()), "wgrad_tn_colsum")
+        return out, cs
     _check(L.wgrad_tn(a.shape[0], M, N, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(bool(accumulate)), _ptr(ws), _stream()),
            "wgrad_tn")
     return out
+
+
+SKINNY_MAX = 16        # input / output features up to which a Linear's weight gradient takes the streaming kernel
+SKINNY_MIN_ROWS = 4096
+
+
+def _skinny_ok(s, x):
+    return (s.is_cuda and s.dtype == torch.float32 and x.dtype == torch.float32 and s.dim() == 2 and x.dim() == 2 and s.shape[0] == x.shape[0]
+            and s.shape[0] >= SKINNY_MIN_ROWS and 1 <= s.shape[1] <= SKINNY_MAX and x.shape[1] % 64 == 0 and 64 <= x.shape[1] <= 1024
+            and s.stride(1) == 1 and x.stride(1) == 1)
+
+
+def wgrad_skinny(s, x, transposed=False, colsum_x=False, colsum_s=False):
+    """s^T x for s (R, NS <= 16), x (R, F): (NS, F), or (F, NS) when transposed; optionally x.sum(0) and s.sum(0) from the same
+    pass (csrc/mappo_ops.hip k_wgrad_skinny).  Returns (C, colsum_x or None, colsum_s or None)."""
+    if not _skinny_ok(s, x):
+        C = torch.mm(s.t(), x)
+        return (C.t().contiguous() if transposed else C), (x.sum(0) if colsum_x else None), (s.sum(0) if colsum_s else None)
+    L = load_library()
+    R, NS, F = s.shape[0], s.shape[1], x.shape[1]
+    C = torch.empty((F, NS) if transposed else (NS, F), dtype=torch.float32, device=x.device)
+    cx = torch.empty(F, dtype=torch.float32, device=x.device) if colsum_x else None
+    cs = torch.empty(NS, dtype=torch.float32, device=x.device) if colsum_s else None
+    ws = torch.empty(L.wgrad_skinny_workspace(NS, F), dtype=torch.uint8, device=x.device)
+    _check(L.wgrad_skinny(R, NS, F, _ptr(s), s.stride(0), _ptr(x), x.stride(0), int(bool(transposed)), _ptr(C), _ptr(cx), _ptr(cs), _ptr(ws),
+                          _stream()), "wgrad_skinny")
+    return C, cx, cs
+
+
+class _SkinnyLinear(torch.autograd.Function):
+    """x W^T + b for a Linear with at most SKINNY_MAX inputs or outputs: forward and input gradient are the library's GEMMs,
+    weight and bias gradient one streaming pass (wgrad_skinny)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = x.reshape(-1, W.shape[1])          # a permuted input is gathered once, here; backward reuses the copy
+        ctx.save_for_backward(x2, W)
+        ctx.has_bias = b is not None
+        ctx.x_shape = x.shape
+        y = torch.empty(x.shape[:-1] + (W.shape[0],), dtype=x.dtype, device=x.device)   # a base tensor: callers may consume it in place
+        if b is None:
+            torch.mm(x2, W.t(), out=y.view(-1, W.shape[0]))
+        else:
+            torch.addmm(b, x2, W.t(), out=y.view(-1, W.shape[0]))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, W = ctx.saved_tensors
+        n_out, n_in = W.shape
+        g2 = g.reshape(-1, n_out)
+        if g2.stride(1) != 1:
+            g2 = g2.contiguous()
+        dx = torch.mm(g2, W).reshape(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            if n_in <= SKINNY_MAX and n_in <= n_out:   # few inputs: dW [n_out][n_in] = g^T x, lanes over g's columns
+                dW, db, _ = wgrad_skinny(x2, g2, transposed=True, colsum_x=want_db)
+            else:                                      # few outputs: dW [n_out][n_in], lanes over x's columns
+                dW, _, db = wgrad_skinny(g2, x2, transposed=False, colsum_s=want_db)
+        return dx, dW, db
+
+
+def linear_skinny(x, W, b=None):
+    """F.linear for layers with at most SKINNY_MAX inputs or outputs (the position part of DHGN's semantic layer, the action and
+    value heads); under autograd the weight / bias gradients use wgrad_skinny."""
+    if torch.is_grad_enabled() and (W.requires_grad or (b is not None and b.requires_grad) or x.requires_grad) and x.is_cuda:
+        return _SkinnyLinear.apply(x, W, b)
+    return F.linear(x, W, b)
 
 
 def _linear_fwd(x, W, b, out=None, relu=False, consume_addend=False):
@@ -472,9 +554,14 @@ class _Linear(torch.autograd.Function):
         g2 = g.reshape(-1, W.shape[0])
         x2 = x.reshape(-1, W.shape[1])
         dx = torch.mm(g2, W).reshape(x.shape) if ctx.needs_input_grad[0] else None
-        dW = wgrad(g2, x2) if ctx.needs_input_grad[1] else None
-        db = None
-        if ctx.bias_kind and ctx.needs_input_grad[2]:
+        dW = db = None
+        want_db = bool(ctx.bias_kind and ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[1]:
+            if want_db and ctx.bias_kind == 1:
+                dW, db = wgrad(g2, x2, colsum=True)   # the bias gradient rides in the weight-gradient kernel's pass over g
+            else:
+                dW = wgrad(g2, x2)
+        if want_db and db is None:
             db = g2.sum(0) if ctx.bias_kind == 1 else g.reshape(ctx.b_shape)
         return dx, dW, db, None, None
 

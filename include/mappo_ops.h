@@ -212,6 +212,21 @@ int rollout_record(int32_t N, int32_t n_items, const mo_record_item *items, cons
 int64_t wgrad_tn_workspace(int32_t M, int32_t N);
 int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
              void *workspace, void *stream);
+/* Same, and colsum_a [M] = sum_k A[k][:] (OVERWRITTEN) from the same pass over A: with A = grad_output that is the bias gradient
+ * `grad_output.sum(0)` of the Linear layer, which autograd otherwise gets from a second full read of grad_output. */
+int wgrad_tn_colsum(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
+                    float *colsum_a, void *workspace, void *stream);
+
+/*
+ * Weight gradient of a Linear layer with at most 16 inputs or outputs (the K = 4 position part of DHGN's semantic layer, the action
+ * and value heads; autograd's `grad_output.t() @ input`, DHGN/mappo_parallel.py:660-708) as one streaming pass:
+ *   C [NS][F] = sum_r S[r][:]^T X[r][:]   (transposed != 0: C [F][NS]);  S [R][NS] (lds), X [R][F] (ldx), F a multiple of 64.
+ * colsum_x [F] = sum_r X[r][:], colsum_s [NS] = sum_r S[r][:] (NULL skips): the bias gradient, whichever operand is grad_output.
+ * Deterministic (per-workgroup partials in `workspace` >= wgrad_skinny_workspace(NS, F) bytes, reduced in a fixed order in f64).
+ */
+int64_t wgrad_skinny_workspace(int32_t NS, int32_t F);
+int wgrad_skinny(int64_t R, int32_t NS, int32_t F, const float *S, int64_t lds, const float *X, int64_t ldx, int32_t transposed, float *C,
+                 float *colsum_x, float *colsum_s, void *workspace, void *stream);
 
 const char *mappo_ops_error_string(int code);
 

@@ -172,6 +172,11 @@ def test_wgrad_matches_f64_reference(K, M, N, pad):
     acc = base.clone()
     ops.wgrad(a, b, out=acc, accumulate=True)
     assert (acc.double() - (ref + base.double())).abs().max().item() < 2e-5 * scale + 1e-5
+    # the bias gradient from the same pass over a: the product is unchanged bit for bit, the column sums match float64
+    got2, cs = ops.wgrad(a, b, colsum=True)
+    assert torch.equal(got2, got)
+    assert (cs.double() - a.double().sum(0)).abs().max().item() < 2e-5 * scale
+    assert torch.equal(ops.wgrad(a, b, colsum=True)[1], cs)
 
 
 @pytest.mark.gpu
@@ -180,6 +185,9 @@ def test_wgrad_unsupported_shapes_use_blas():
     a = torch.randn((5000, 9), device="cuda")
     b = torch.randn((5000, 128), device="cuda")
     torch.testing.assert_close(ops.wgrad(a, b), a.t() @ b, rtol=1e-4, atol=1e-3)
+    dW, cs = ops.wgrad(a, b, colsum=True)
+    torch.testing.assert_close(dW, a.t() @ b, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(cs, a.sum(0), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.gpu
@@ -478,3 +486,33 @@ def test_spectral_norm_weight_matches_torch_hook(A, H):
         w = ops.spectral_norm_weight(W, u, v, 1e-12, 0)
         assert torch.equal(u, u0) and torch.equal(v, v0)
         assert torch.allclose(w.cpu().double(), lin.weight.detach(), rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("R,n_in,n_out", [(492000, 128, 9), (492000, 128, 1), (492000, 4, 128), (5003, 128, 16), (4100, 8, 64)])
+def test_skinny_linear_autograd_matches_torch(R, n_in, n_out):
+    """ops.linear_skinny (weight / bias gradient in the streaming kernel k_wgrad_skinny) against torch.nn.functional.linear with
+    float64 gradients as the reference; permuted input, a column slice of a larger weight, run-to-run determinism."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(R + n_in)
+    T = 4 if R % 4 == 0 else 1
+    x = torch.randn((T, R // T, n_in), generator=g, device="cuda").permute(1, 0, 2)       # non-contiguous rows, like the GRU features
+    Wfull = torch.randn((n_out, n_in + 3), generator=g, device="cuda", requires_grad=True)
+    bias = torch.randn((n_out,), generator=g, device="cuda", requires_grad=True)
+    xg = x.clone().requires_grad_(n_in > 16)
+    gout = torch.randn((R // T, T, n_out), generator=g, device="cuda")
+    y = ops.linear_skinny(xg, Wfull[:, 3:], bias)
+    y.backward(gout)
+    got = (y.detach().clone(), Wfull.grad.clone(), bias.grad.clone(), None if xg.grad is None else xg.grad.clone())
+    Wfull.grad = bias.grad = None
+    y1 = ops.linear_skinny(xg, Wfull[:, 3:], bias); y1.backward(gout)
+    assert torch.equal(Wfull.grad, got[1]) and torch.equal(bias.grad, got[2])
+    x64, W64, b64 = x.double(), Wfull.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    x64.requires_grad_(n_in > 16)
+    y2 = torch.nn.functional.linear(x64, W64[:, 3:], b64)
+    y2.backward(gout.double())
+    scale = float(R) ** 0.5
+    assert (got[0].double() - y2.detach()).abs().max() < 1e-4 * (1 + n_in ** 0.5)
+    assert (got[1].double() - W64.grad).abs().max() < 2e-5 * scale
+    assert (got[2].double() - b64.grad).abs().max() < 2e-5 * scale
+    if got[3] is not None:
+        assert (got[3].double() - x64.grad).abs().max() < 1e-4 * (1 + n_out ** 0.5)
