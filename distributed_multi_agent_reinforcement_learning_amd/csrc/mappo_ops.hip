@@ -1265,17 +1265,13 @@ __device__ __forceinline__ void wgrad_load(WgradRegs<AM, BN, U> &r, const float 
     }
 }
 
-template <int AM, int BN, int U, bool CS>
-__device__ __forceinline__ void wgrad_mma(const WgradRegs<AM, BN, U> &r, v4f (&acc)[AM][4][BN][4], float (&cs)[AM][4]) {
+template <int AM, int BN, int U>
+__device__ __forceinline__ void wgrad_mma(const WgradRegs<AM, BN, U> &r, v4f (&acc)[AM][4][BN][4]) {
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
         for (int a = 0; a < AM; a++) {
             const float av[4] = {r.a[u][a].x, r.a[u][a].y, r.a[u][a].z, r.a[u][a].w};
-            if (CS) {  // column sums of A (the bias gradient) ride in VALU slots beside the MFMAs
-#pragma unroll
-                for (int t = 0; t < 4; t++) cs[a][t] += av[t];
-            }
 #pragma unroll
             for (int b = 0; b < BN; b++) {
                 const float bv[4] = {r.b[u][b].x, r.b[u][b].y, r.b[u][b].z, r.b[u][b].w};
@@ -1287,9 +1283,9 @@ __device__ __forceinline__ void wgrad_mma(const WgradRegs<AM, BN, U> &r, v4f (&a
         }
 }
 
-template <int AM, int BN, bool CS>
+template <int AM, int BN>
 __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int64_t K,
-                                               int M, int N, float *__restrict__ part, float *__restrict__ part_cs) {
+                                               int M, int N, float *__restrict__ part) {
     constexpr int U = 4;  // k-steps per pipeline stage (measured: 2 exposes load latency, 6+ lengthens the unpipelined ends)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 15, kk = lane >> 4;
@@ -1308,11 +1304,6 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
             for (int b = 0; b < BN; b++)
 #pragma unroll
                 for (int v = 0; v < 4; v++) acc[a][t][b][v] = (v4f){0.f, 0.f, 0.f, 0.f};
-    float cs[AM][4];
-#pragma unroll
-    for (int a = 0; a < AM; a++)
-#pragma unroll
-        for (int t = 0; t < 4; t++) cs[a][t] = 0.f;
     // Straight-line pipeline (no branch around a load: the s_waitcnt counts stay exact): pairs of U-step chunks, the
     // loads of the chunk after next are issued before the MFMAs of the current one; past the end the last chunk is
     // re-loaded (discarded) instead of branching.
@@ -1322,14 +1313,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
     for (int64_t c = 0; c < pairs; c++) {
         wgrad_load<AM, BN, U>(r1, pa + U * lda4, pb + U * ldb4, lda4, ldb4);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler would sink it to its use)
-        wgrad_mma<AM, BN, U, CS>(r0, acc, cs);
+        wgrad_mma<AM, BN, U>(r0, acc);
         __builtin_amdgcn_sched_barrier(0);
         const int64_t adv = (c + 1 < pairs) ? 2 * U : U;
         pa += adv * lda4;
         pb += adv * ldb4;
         wgrad_load<AM, BN, U>(r0, pa, pb, lda4, ldb4);
         __builtin_amdgcn_sched_barrier(0);
-        wgrad_mma<AM, BN, U, CS>(r1, acc, cs);
+        wgrad_mma<AM, BN, U>(r1, acc);
         __builtin_amdgcn_sched_barrier(0);
     }
     {   // the n_s % 2U left-over steps, then (last workgroup) the K % 4 tail rows, zero-filled
@@ -1338,7 +1329,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
         WgradRegs<AM, BN, 1> r;
         for (int64_t s = s_beg + pairs * 2 * U; s < s_end; s++) {
             wgrad_load<AM, BN, 1>(r, pa, pb, lda4, ldb4);
-            wgrad_mma<AM, BN, 1, CS>(r, acc, cs);
+            wgrad_mma<AM, BN, 1>(r, acc);
             pa += lda4;
             pb += ldb4;
         }
@@ -1348,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
             for (int a = 0; a < AM; a++) r.a[0][a] = live ? *(const float4 *)(pa + a * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int b = 0; b < BN; b++) r.b[0][b] = live ? *(const float4 *)(pb + b * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wgrad_mma<AM, BN, 1, CS>(r, acc, cs);
+            wgrad_mma<AM, BN, 1>(r, acc);
         }
     }
     // D tile (a,t | b,v): lane l, register q holds row 4 (l / 16) + q, column l % 16 of the tile, i.e. output row
@@ -1364,38 +1355,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
                 for (int b = 0; b < BN; b++)
                     *(float4 *)(po + (size_t)(64 * a + 4 * q + t) * N + 64 * b) =
                         make_float4(acc[a][t][b][0][q], acc[a][t][b][1][q], acc[a][t][b][2][q], acc[a][t][b][3][q]);
-    if (CS) {  // this lane summed columns m0 + 64 a + 4 i + t over its rows (k-step row kk): fold the four kk groups, one store
-#pragma unroll
-        for (int a = 0; a < AM; a++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                cs[a][t] += __shfl_xor(cs[a][t], 16);
-                cs[a][t] += __shfl_xor(cs[a][t], 32);
-            }
-        if (blockIdx.z == 0 && (wave & 1) == 0 && kk == 0) {
-#pragma unroll
-            for (int a = 0; a < AM; a++)
-                *(float4 *)(part_cs + (size_t)blockIdx.x * M + m0 + 64 * a + 4 * i) = make_float4(cs[a][0], cs[a][1], cs[a][2], cs[a][3]);
-        }
-    }
 }
 
 // C[m][n] = (accumulate ? C[m][n] : 0) + sum_x part[x][m][n], x ascending: the same order every run
-// (threads MN .. MN + M - 1: the column sums of A, colsum[m] = sum_x part_cs[x][m], when requested)
-__global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float *__restrict__ part, float *__restrict__ C, int accumulate,
-                                                      int M, const float *__restrict__ part_cs, float *__restrict__ colsum) {
+__global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float *__restrict__ part, float *__restrict__ C, int accumulate) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= MN) {
-        const int m = idx - MN;
-        if (colsum != nullptr && m < M) {
-            float c0 = 0.f, c1 = 0.f;
-            int x = 0;
-            for (; x + 2 <= S; x += 2) { c0 += part_cs[(size_t)x * M + m]; c1 += part_cs[(size_t)(x + 1) * M + m]; }
-            if (x < S) c0 += part_cs[(size_t)x * M + m];
-            colsum[m] = c0 + c1;
-        }
-        return;
-    }
+    if (idx >= MN) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int x = 0;
     for (; x + 4 <= S; x += 4) {
@@ -1407,6 +1372,61 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float
     for (; x < S; x++) s0 += part[(size_t)x * MN + idx];
     const float s = (s0 + s1) + (s2 + s3);
     C[idx] = accumulate ? C[idx] + s : s;
+}
+
+// ---- ReLU backward + bias gradient in one pass ------------------------------------------------------------------------------
+// gin = gout * [y > 0] (aten::threshold_backward on the saved output) and colsum[f] = sum_r gin[r][f] (the bias gradient of the
+// Linear in front of the ReLU): autograd reads gin a second time for the sum (756 MB per mini-batch at DHGN's AGG layer);
+// here it is added up while it is written.  F a multiple of 4, <= 1024; rows of F contiguous floats.
+constexpr int RB_BLOCKS = 2048, RB_TPB = 256;
+__global__ __launch_bounds__(RB_TPB) void k_relu_bwd_colsum(int64_t R, int F, const float *__restrict__ gout, const float *__restrict__ y,
+                                                            float *__restrict__ gin, float *__restrict__ part) {
+    __shared__ float4 s_sum[RB_TPB];
+    const int f4 = F >> 2;                 // float4 columns per row
+    const int cpb = RB_TPB / f4;           // rows a workgroup covers per step (host: f4 divides RB_TPB)
+    const int col = threadIdx.x % f4, rr = threadIdx.x / f4;
+    const int64_t rpb = (R + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *g4 = (const float4 *)gout, *y4 = (const float4 *)y;
+    float4 *o4 = (float4 *)gin;
+    int64_t r = r0 + rr;
+    for (; r + 3 * cpb < r1; r += 4 * cpb) {  // four rows in flight per lane
+        float4 g[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { g[u] = g4[(r + u * cpb) * f4 + col]; v[u] = y4[(r + u * cpb) * f4 + col]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float4 o;
+            o.x = v[u].x > 0.f ? g[u].x : 0.f; o.y = v[u].y > 0.f ? g[u].y : 0.f; o.z = v[u].z > 0.f ? g[u].z : 0.f; o.w = v[u].w > 0.f ? g[u].w : 0.f;
+            o4[(r + u * cpb) * f4 + col] = o;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+    }
+    for (; r < r1; r += cpb) {
+        const float4 g = g4[r * f4 + col], v = y4[r * f4 + col];
+        float4 o;
+        o.x = v.x > 0.f ? g.x : 0.f; o.y = v.y > 0.f ? g.y : 0.f; o.z = v.z > 0.f ? g.z : 0.f; o.w = v.w > 0.f ? g.w : 0.f;
+        o4[r * f4 + col] = o;
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    if (rr == 0) {
+        for (int k = 1; k < cpb; k++) {
+            const float4 t = s_sum[k * f4 + col];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        ((float4 *)(part + (size_t)blockIdx.x * F))[col] = acc;
+    }
+}
+
+__global__ void k_colsum_reduce(int nblk, int F, const float *__restrict__ part, float *__restrict__ colsum) {
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= F) return;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * F + idx];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) colsum[idx] = (float)s;
 }
 
 // ---- skinny weight gradient: C [NS][F] = S^T X over R rows, S [R][NS] with NS <= 16 -----------------------------------------
@@ -1720,37 +1740,36 @@ int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float 
 int64_t wgrad_tn_workspace(int32_t M, int32_t N) {
     if (M < 128 || N < 128 || (M & 127) || (N & 127)) return -1;
     int am, bn;
-    return (int64_t)wgrad_split(M, N, &am, &bn) * ((int64_t)M * N + M) * sizeof(float);
+    return (int64_t)wgrad_split(M, N, &am, &bn) * M * N * sizeof(float);
 }
 
 int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
              void *workspace, void *stream) {
-    return wgrad_tn_colsum(K, M, N, A, lda, B, ldb, C, accumulate, nullptr, workspace, stream);
-}
-
-int wgrad_tn_colsum(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
-                    float *colsum_a, void *workspace, void *stream) {
     if (K < 1 || M < 128 || N < 128 || (M & 127) || (N & 127) || M > 1024 || N > 1024 || !A || !B || !C || !workspace) return MO_ERR_BAD_ARG;
     if (lda < M || ldb < N || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return MO_ERR_BAD_ARG;
     int am, bn;
     const int S = wgrad_split(M, N, &am, &bn);
     const dim3 grid(S, M / (128 * am), N / (128 * bn));
     hipStream_t st = (hipStream_t)stream;
-    float *part = (float *)workspace, *part_cs = part + (size_t)S * M * N;
-#define WGRAD_LAUNCH(AM, BN, CS) hipLaunchKernelGGL((k_wgrad<AM, BN, CS>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part, part_cs)
-    if (colsum_a) {
-        if (am == 3) WGRAD_LAUNCH(3, 1, true);
-        else if (bn == 3) WGRAD_LAUNCH(1, 3, true);
-        else WGRAD_LAUNCH(1, 1, true);
-    } else {
-        if (am == 3) WGRAD_LAUNCH(3, 1, false);
-        else if (bn == 3) WGRAD_LAUNCH(1, 3, false);
-        else WGRAD_LAUNCH(1, 1, false);
-    }
-#undef WGRAD_LAUNCH
-    const int threads = M * N + (colsum_a ? M : 0);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((threads + 255) / 256), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate, (int)M,
-                       (const float *)part_cs, colsum_a);
+    float *part = (float *)workspace;
+    if (am == 3) hipLaunchKernelGGL((k_wgrad<3, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
+    else if (bn == 3) hipLaunchKernelGGL((k_wgrad<1, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
+    else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate);
+    return (int)hipGetLastError();
+}
+
+int64_t relu_bwd_colsum_workspace(int32_t F) { return (int64_t)RB_BLOCKS * F * sizeof(float); }
+
+int relu_bwd_colsum(int64_t R, int32_t F, const float *gout, const float *y, float *gin, float *colsum, void *workspace, void *stream) {
+    if (R < 1 || F < 4 || (F & 3) || F > 1024 || (RB_TPB % (F >> 2)) || !gout || !y || !gin || !colsum || !workspace) return MO_ERR_BAD_ARG;
+    if ((((uintptr_t)gout | (uintptr_t)y | (uintptr_t)gin) & 15)) return MO_ERR_BAD_ARG;
+    const int64_t rows_per_step = RB_TPB / (F >> 2);
+    int64_t want = (R + rows_per_step - 1) / rows_per_step;
+    const int grid = want < RB_BLOCKS ? (int)want : RB_BLOCKS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_relu_bwd_colsum, dim3(grid), dim3(RB_TPB), 0, st, R, (int)F, gout, y, gin, (float *)workspace);
+    hipLaunchKernelGGL(k_colsum_reduce, dim3((F + 3) / 4), dim3(256), 0, st, grid, (int)F, (const float *)workspace, colsum);
     return (int)hipGetLastError();
 }
 

@@ -59,7 +59,9 @@ def load_library():
         L.wgrad_tn_workspace.argtypes = [i32, i32]
         L.wgrad_tn_workspace.restype = i64
         L.wgrad_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
-        L.wgrad_tn_colsum.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp, vp]
+        L.relu_bwd_colsum_workspace.argtypes = [i32]
+        L.relu_bwd_colsum_workspace.restype = i64
+        L.relu_bwd_colsum.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
         L.wgrad_skinny_workspace.argtypes = [i32, i32]
         L.wgrad_skinny_workspace.restype = i64
         L.wgrad_skinny.argtypes = [i64, i32, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp]
@@ -405,17 +407,14 @@ def _wgrad_ok(a, b):
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
-def wgrad(a, b, out=None, accumulate=False, colsum=False):
+def wgrad(a, b, out=None, accumulate=False):
     """a^T b for a (K, M), b (K, N) row-major (rows may be strided): the weight gradient of a Linear / GRU projection over
     the K rows of a minibatch (the `grad_output.t() @ input` of autograd, DHGN/mappo_parallel.py:660-708).  Shapes the
-    split-K MFMA kernel covers (M, N multiples of 128) run in csrc/mappo_ops.hip k_wgrad, the rest in the BLAS library.
-    colsum: also return a.sum(0) (the bias gradient when a = grad_output), computed in the same pass over a."""
+    split-K MFMA kernel covers (M, N multiples of 128) run in csrc/mappo_ops.hip k_wgrad, the rest in the BLAS library."""
     if not _wgrad_ok(a, b):
         if out is None:
-            res = torch.mm(a.t(), b)
-        else:
-            res = out.addmm_(a.t(), b) if accumulate else torch.mm(a.t(), b, out=out)
-        return (res, a.sum(0)) if colsum else res
+            return torch.mm(a.t(), b)
+        return out.addmm_(a.t(), b) if accumulate else torch.mm(a.t(), b, out=out)
     L = load_library()
     M, N = a.shape[1], b.shape[1]
     if out is None:
@@ -423,14 +422,29 @@ def wgrad(a, b, out=None, accumulate=False, colsum=False):
         accumulate = False
     assert out.is_contiguous() and out.shape == (M, N)
     ws = torch.empty(L.wgrad_tn_workspace(M, N), dtype=torch.uint8, device=a.device)
-    if colsum:
-        cs = torch.empty(M, dtype=a.dtype, device=a.device)
-        _check(L.wgrad_tn_colsum(a.shape[0], M, N, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(bool(accumulate)), _ptr(cs), _ptr(ws),
-                                 _stream()), "wgrad_tn_colsum")
-        return out, cs
     _check(L.wgrad_tn(a.shape[0], M, N, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(bool(accumulate)), _ptr(ws), _stream()),
            "wgrad_tn")
     return out
+
+
+RELU_BWD_MIN_ROWS = 4096
+
+
+def relu_bwd_colsum(g, y):
+    """(g * (y > 0), its column sums): ReLU backward from the saved output and the bias gradient of the Linear in front of it
+    in one pass (csrc/mappo_ops.hip k_relu_bwd_colsum); small or odd shapes take the two torch ops."""
+    F_ = g.shape[-1]
+    rows = g.numel() // max(F_, 1)
+    if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and y.is_contiguous() and y.shape == g.shape and rows >= RELU_BWD_MIN_ROWS
+            and F_ % 4 == 0 and F_ <= 1024 and 256 % (F_ // 4) == 0 and g.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
+        gin = torch.ops.aten.threshold_backward(g, y, 0.0)
+        return gin, gin.reshape(-1, F_).sum(0)
+    L = load_library()
+    gin = torch.empty_like(g)
+    cs = torch.empty(F_, dtype=g.dtype, device=g.device)
+    ws = torch.empty(L.relu_bwd_colsum_workspace(F_), dtype=torch.uint8, device=g.device)
+    _check(L.relu_bwd_colsum(rows, F_, _ptr(g), _ptr(y), _ptr(gin), _ptr(cs), _ptr(ws), _stream()), "relu_bwd_colsum")
+    return gin, cs
 
 
 SKINNY_MAX = 16        # input / output features up to which a Linear's weight gradient takes the streaming kernel
@@ -549,18 +563,17 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, W, y = ctx.saved_tensors
-        if ctx.relu:
-            g = torch.ops.aten.threshold_backward(g, y, 0.0)  # relu'(pre-activation) from the saved output
+        db = None
+        want_db = bool(ctx.bias_kind and ctx.needs_input_grad[2])
+        if ctx.relu:  # relu'(pre-activation) from the saved output; with a 1-D bias its gradient comes out of the same pass
+            if want_db and ctx.bias_kind == 1:
+                g, db = relu_bwd_colsum(g.contiguous(), y)
+            else:
+                g = torch.ops.aten.threshold_backward(g, y, 0.0)
         g2 = g.reshape(-1, W.shape[0])
         x2 = x.reshape(-1, W.shape[1])
         dx = torch.mm(g2, W).reshape(x.shape) if ctx.needs_input_grad[0] else None
-        dW = db = None
-        want_db = bool(ctx.bias_kind and ctx.needs_input_grad[2])
-        if ctx.needs_input_grad[1]:
-            if want_db and ctx.bias_kind == 1:
-                dW, db = wgrad(g2, x2, colsum=True)   # the bias gradient rides in the weight-gradient kernel's pass over g
-            else:
-                dW = wgrad(g2, x2)
+        dW = wgrad(g2, x2) if ctx.needs_input_grad[1] else None
         if want_db and db is None:
             db = g2.sum(0) if ctx.bias_kind == 1 else g.reshape(ctx.b_shape)
         return dx, dW, db, None, None

@@ -212,10 +212,15 @@ int rollout_record(int32_t N, int32_t n_items, const mo_record_item *items, cons
 int64_t wgrad_tn_workspace(int32_t M, int32_t N);
 int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
              void *workspace, void *stream);
-/* Same, and colsum_a [M] = sum_k A[k][:] (OVERWRITTEN) from the same pass over A: with A = grad_output that is the bias gradient
- * `grad_output.sum(0)` of the Linear layer, which autograd otherwise gets from a second full read of grad_output. */
-int wgrad_tn_colsum(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
-                    float *colsum_a, void *workspace, void *stream);
+/*
+ * ReLU backward and the bias gradient of the Linear in front of it in one pass (autograd: aten::threshold_backward, then
+ * grad.sum(0) re-reading it; MAPPO.train's loss.backward(), DHGN/mappo_parallel.py:660-708):
+ *   gin [R][F] = gout * [y > 0] (y = the saved ReLU output);  colsum [F] = sum_r gin[r][:].
+ * Rows are F contiguous floats, F a multiple of 4 with F/4 dividing 256; 16-byte aligned pointers.  Deterministic
+ * (per-workgroup partials in `workspace` >= relu_bwd_colsum_workspace(F) bytes, reduced in a fixed order in f64).
+ */
+int64_t relu_bwd_colsum_workspace(int32_t F);
+int relu_bwd_colsum(int64_t R, int32_t F, const float *gout, const float *y, float *gin, float *colsum, void *workspace, void *stream);
 
 /*
  * Weight gradient of a Linear layer with at most 16 inputs or outputs (the K = 4 position part of DHGN's semantic layer, the action

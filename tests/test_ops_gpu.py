@@ -172,11 +172,6 @@ def test_wgrad_matches_f64_reference(K, M, N, pad):
     acc = base.clone()
     ops.wgrad(a, b, out=acc, accumulate=True)
     assert (acc.double() - (ref + base.double())).abs().max().item() < 2e-5 * scale + 1e-5
-    # the bias gradient from the same pass over a: the product is unchanged bit for bit, the column sums match float64
-    got2, cs = ops.wgrad(a, b, colsum=True)
-    assert torch.equal(got2, got)
-    assert (cs.double() - a.double().sum(0)).abs().max().item() < 2e-5 * scale
-    assert torch.equal(ops.wgrad(a, b, colsum=True)[1], cs)
 
 
 @pytest.mark.gpu
@@ -185,9 +180,6 @@ def test_wgrad_unsupported_shapes_use_blas():
     a = torch.randn((5000, 9), device="cuda")
     b = torch.randn((5000, 128), device="cuda")
     torch.testing.assert_close(ops.wgrad(a, b), a.t() @ b, rtol=1e-4, atol=1e-3)
-    dW, cs = ops.wgrad(a, b, colsum=True)
-    torch.testing.assert_close(dW, a.t() @ b, rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(cs, a.sum(0), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.gpu
@@ -516,3 +508,21 @@ def test_skinny_linear_autograd_matches_torch(R, n_in, n_out):
     assert (got[2].double() - b64.grad).abs().max() < 2e-5 * scale
     if got[3] is not None:
         assert (got[3].double() - x64.grad).abs().max() < 1e-4 * (1 + n_out ** 0.5)
+
+
+@pytest.mark.parametrize("R,F", [(1476000, 128), (4099, 128), (5000, 64), (4096, 256), (300, 128), (5000, 36)])
+def test_relu_backward_with_bias_gradient_matches_torch(R, F):
+    """relu_bwd_colsum (one pass) against aten::threshold_backward (bit-identical) and a float64 column sum; shapes the kernel
+    does not cover take the torch ops (same results)."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(R + F)
+    gout = torch.randn((R, F), generator=g, device="cuda")
+    y = torch.relu(torch.randn((R, F), generator=g, device="cuda"))
+    gin, cs = ops.relu_bwd_colsum(gout, y)
+    want = torch.ops.aten.threshold_backward(gout, y, 0.0)
+    assert torch.equal(gin, want)
+    ref = torch.zeros(F, dtype=torch.float64, device="cuda")
+    for s0 in range(0, R, 262144):
+        ref += want[s0:s0 + 262144].double().sum(0)
+    assert (cs.double() - ref).abs().max().item() < 2e-5 * float(R) ** 0.5
+    assert torch.equal(ops.relu_bwd_colsum(gout, y)[1], cs)
