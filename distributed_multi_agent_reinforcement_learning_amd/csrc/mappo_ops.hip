@@ -1374,6 +1374,74 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float
     C[idx] = accumulate ? C[idx] + s : s;
 }
 
+// ---- neighbour mean of the fixed-depth recursive aggregation (DHGN.fcra, DHGN/mappo_parallel.py:204-233) ----------------------
+// out[r][i][:] = act( sum_j abar_ij z[r][j][:] + bias ),  abar = adj / max(sum_j |adj|, 1e-12)  (F.normalize(adj, p=1, dim=-1))
+// for the actor, abar = 1 / P for the critic (normalize(ones_like(adj))): the reference's torch.matmul(abar, hist) -- a batched
+// P x P x E product per row, which the library runs as a strided-batched GEMM after the caller gathered the history slice into a
+// contiguous copy.  Here: one pass, lane = feature, the P neighbour vectors of a row in registers, the P x P weights computed
+// one per lane and read back with v_readlane; rows may be strided slices (n, t) of a (N, T + depth, P, E) history buffer.
+// Both aggregates (actor from za, critic from zc) can come out of one launch (the rollout's paired tick).
+struct NbrArgs {
+    int R, P, E, T, relu;              // row r = (n, t) = (r / T, r % T)
+    int64_t za_es, za_ts, zc_es, zc_ts;  // element strides of an episode / a step in za, zc
+    int64_t adj_rs;                     // elements between adjacency rows
+};
+template <int PT>
+__global__ void k_nbr_mean(NbrArgs a, const float *__restrict__ za, const float *__restrict__ zc, const float *__restrict__ adj,
+                           const float *__restrict__ bias, float *__restrict__ out_a, float *__restrict__ out_c) {
+    const int P = a.P, E = a.E, f = threadIdx.x, lane = threadIdx.x & 63;
+    const float bf = bias ? bias[f] : 0.f;
+    const float inv_p = 1.f / fmaxf((float)P, 1e-12f);
+    for (int r = blockIdx.x; r < a.R; r += gridDim.x) {
+        const int n = r / a.T, t = r - n * a.T;
+        if (out_a) {
+            const float *zr = za + (size_t)n * a.za_es + (size_t)t * a.za_ts;
+            float z[PT];
+#pragma unroll
+            for (int j = 0; j < PT; j++) z[j] = j < P ? zr[(size_t)j * E + f] : 0.f;
+            // weights: lane l = i P + j (P P <= 64) holds adj[i][j] / max(sum_j |adj[i][j]|, eps)
+            float w = 0.f;
+            if (P * P <= 64) {
+                const float av = lane < P * P ? adj[(size_t)r * a.adj_rs + lane] : 0.f;
+                const int li = lane / P < P ? lane / P : P - 1;
+                float nrm = 0.f;
+                for (int j = 0; j < P; j++) nrm += fabsf(__shfl(av, li * P + j));
+                w = av / fmaxf(nrm, 1e-12f);
+            }
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+                if (i < P) {
+                    float acc = 0.f;
+                    if (P * P <= 64) {
+#pragma unroll
+                        for (int j = 0; j < PT; j++)
+                            if (j < P) acc = __builtin_fmaf(rl_f(w, i * P + j), z[j], acc);
+                    } else {  // P > 8: weights through uniform addresses
+                        const float *ar = adj + (size_t)r * a.adj_rs + (size_t)i * P;
+                        float nrm = 0.f;
+                        for (int j = 0; j < P; j++) nrm += fabsf(ar[j]);
+                        nrm = fmaxf(nrm, 1e-12f);
+#pragma unroll
+                        for (int j = 0; j < PT; j++)
+                            if (j < P) acc = __builtin_fmaf(ar[j] / nrm, z[j], acc);
+                    }
+                    acc += bf;
+                    out_a[((size_t)r * P + i) * E + f] = a.relu ? fmaxf(acc, 0.f) : acc;
+                }
+        }
+        if (out_c) {
+            const float *zr = zc + (size_t)n * a.zc_es + (size_t)t * a.zc_ts;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < PT; j++)
+                if (j < P) acc = __builtin_fmaf(inv_p, zr[(size_t)j * E + f], acc);
+            acc += bf;
+            acc = a.relu ? fmaxf(acc, 0.f) : acc;
+            for (int i = 0; i < P; i++) out_c[((size_t)r * P + i) * E + f] = acc;
+        }
+    }
+}
+
 // ---- ReLU backward + bias gradient in one pass ------------------------------------------------------------------------------
 // gin = gout * [y > 0] (aten::threshold_backward on the saved output) and colsum[f] = sum_r gin[r][f] (the bias gradient of the
 // Linear in front of the ReLU): autograd reads gin a second time for the sum (756 MB per mini-batch at DHGN's AGG layer);
@@ -1756,6 +1824,19 @@ int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const
     else if (bn == 3) hipLaunchKernelGGL((k_wgrad<1, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
     else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate);
+    return (int)hipGetLastError();
+}
+
+int fcra_neighbour_mean(int32_t R, int32_t P, int32_t E, int32_t T, const float *z_actor, int64_t za_episode_stride, int64_t za_step_stride,
+                        const float *z_critic, int64_t zc_episode_stride, int64_t zc_step_stride, const float *adj, int64_t adj_row_stride,
+                        const float *bias, int32_t relu, float *out_actor, float *out_critic, void *stream) {
+    if (R < 0 || P < 1 || P > MAX_P || E < 64 || E > 1024 || (E & 63) || T < 1 || (R % T)) return MO_ERR_BAD_ARG;
+    if ((out_actor && (!z_actor || !adj)) || (out_critic && !z_critic) || (!out_actor && !out_critic)) return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    NbrArgs a{R, P, E, T, relu, za_episode_stride, za_step_stride, zc_episode_stride, zc_step_stride, adj_row_stride};
+    const int grid = R < 16384 ? R : 16384;
+    if (P <= 8) hipLaunchKernelGGL(k_nbr_mean<8>, dim3(grid), dim3(E), 0, (hipStream_t)stream, a, z_actor, z_critic, adj, bias, out_actor, out_critic);
+    else hipLaunchKernelGGL(k_nbr_mean<16>, dim3(grid), dim3(E), 0, (hipStream_t)stream, a, z_actor, z_critic, adj, bias, out_actor, out_critic);
     return (int)hipGetLastError();
 }
 

@@ -187,8 +187,9 @@ class MAPPO:
                        o_state=o_static[n0:n1], q_div=T, p_adj=batch["p_adj"][n0:n1].reshape(R, P, P),
                        e_adj=batch["e_adj"][n0:n1].reshape(R, P, 1), o_adj_bits=batch["o_adj_bits"][n0:n1].reshape(R, P, -1))
             # EmbeddingDataset2 (:95-113): hop k reads the stored embeddings of step t-1-k (clean per-net history)
-            hist_a = [batch["actor_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
-            hist_c = [batch["critic_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T].reshape(R, P, -1) for k in range(d)]
+            # (the (mb, T, P, E) slices are read in place by the neighbour-mean kernel: no gathered copies)
+            hist_a = [batch["actor_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T] for k in range(d)]
+            hist_c = [batch["critic_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T] for k in range(d)]
             # One stream: running the critic branch beside the actor's on a second stream was tried in round 1 and removed --
             # it put two library GEMMs in flight at once, and with DHGN depth > 0 at 4096 environments the update stopped making
             # progress ("two-stream update").  A whole-device library GEMM is not a kernel to co-schedule.

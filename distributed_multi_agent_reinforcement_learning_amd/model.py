@@ -99,11 +99,11 @@ class DHGN(nn.Module):
         E = self.embedding_dim
         if self.depth == 0:
             return h
-        adj = torch.ones_like(adj_p) if is_critic else adj_p
-        abar = F.normalize(adj, p=1, dim=-1)
         for k in range(self.depth):
             aggk = self.AGG_layers[f"AGG_fcra_{k}"]
-            agg = ops.linear(torch.matmul(abar, hist[k]), aggk.weight, aggk.bias, relu=True)
+            # matmul(normalize(adj or ones, p=1), hist[k]): one pass, the history slice read in place (hist is stored data)
+            nb = ops.fcra_mean(z_critic=hist[k]) if is_critic else ops.fcra_mean(z_actor=hist[k], adj=adj_p)
+            agg = ops.linear(nb, aggk.weight, aggk.bias, relu=True)
             Wf = self.FCRA_layers[k].weight  # FCRA_k([agg, h]) as two accumulating GEMMs instead of a concatenation
             last = out is not None and k == self.depth - 1
             h = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias), relu=True,
@@ -137,15 +137,15 @@ class DHGN(nn.Module):
         h0.view(2 * R * P, E).addmm_(emb.view(2 * R * P, 3 * E), Ws[:, ind:].t())
         if self.depth == 0:
             return h0
-        abar_a = F.normalize(adj_p, p=1, dim=-1)
-        abar_c = F.normalize(torch.ones_like(adj_p), p=1, dim=-1)
         h = h0
         for k in range(self.depth):
             aggk = self.AGG_layers[f"AGG_fcra_{k}"]
-            nb = torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
-            torch.matmul(abar_a, hist_a[k], out=nb[0])
-            torch.matmul(abar_c, hist_c[k], out=nb[1])
-            agg = ops.linear(nb, aggk.weight, aggk.bias, relu=True)
+            # relu((abar @ hist) W^T + b) evaluated as relu(abar @ (hist W^T) + b): in the reference's rollout both networks read
+            # the same history list, so the GEMM runs once for the two of them; the two neighbour means, the bias
+            # and the ReLU are one launch
+            za = ops.linear(hist_a[k], aggk.weight)
+            zc = za if hist_c[k] is hist_a[k] or hist_c[k].data_ptr() == hist_a[k].data_ptr() else ops.linear(hist_c[k], aggk.weight)
+            agg = ops.fcra_mean(z_actor=za, z_critic=zc, adj=adj_p, bias=aggk.bias, relu=True)
             Wf = self.FCRA_layers[k].weight
             last = out is not None and k == self.depth - 1
             h = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias), relu=True,

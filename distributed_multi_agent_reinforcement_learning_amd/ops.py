@@ -59,6 +59,7 @@ def load_library():
         L.wgrad_tn_workspace.argtypes = [i32, i32]
         L.wgrad_tn_workspace.restype = i64
         L.wgrad_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
+        L.fcra_neighbour_mean.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, vp, vp, vp]
         L.relu_bwd_colsum_workspace.argtypes = [i32]
         L.relu_bwd_colsum_workspace.restype = i64
         L.relu_bwd_colsum.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
@@ -424,6 +425,48 @@ def wgrad(a, b, out=None, accumulate=False):
     ws = torch.empty(L.wgrad_tn_workspace(M, N), dtype=torch.uint8, device=a.device)
     _check(L.wgrad_tn(a.shape[0], M, N, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(bool(accumulate)), _ptr(ws), _stream()),
            "wgrad_tn")
+    return out
+
+
+def _nbr_view(z):
+    """(pointer tensor, T, episode stride, step stride) of a dense (R, P, E) tensor or an (n, T, P, E) slice of a history buffer"""
+    if z.dim() == 3:
+        assert z.is_contiguous()
+        return z, 1, z.shape[1] * z.shape[2], 0
+    assert z.dim() == 4 and z.stride(3) == 1 and z.stride(2) == z.shape[3]
+    return z, z.shape[1], z.stride(0), z.stride(1)
+
+
+def fcra_mean(z_actor=None, z_critic=None, adj=None, bias=None, relu=False, out=None):
+    """DHGN.fcra's neighbour mean `matmul(normalize(adj, p=1), z)` (actor) and / or `matmul(normalize(ones), z)` (critic), plus an
+    optional bias and ReLU, in one launch (csrc/mappo_ops.hip k_nbr_mean).  z_*: dense (R, P, E) or a (n, T, P, E) slice of a
+    history buffer, read in place.  Returns (R, P, E) for one network, (2, R, P, E) (actor, critic) for both.  No autograd:
+    the inputs are stored data."""
+    L = load_library()
+    z = z_actor if z_actor is not None else z_critic
+    _need_gpu(z, "fcra_neighbour_mean")
+    P, E = z.shape[-2], z.shape[-1]
+    R = z.numel() // (P * E)
+    both = z_actor is not None and z_critic is not None
+    if out is None:
+        out = torch.empty(((2, R, P, E) if both else (R, P, E)), dtype=torch.float32, device=z.device)
+    assert out.is_contiguous() and out.numel() == (2 if both else 1) * R * P * E
+    za = zc = None
+    T = 1
+    a_es = a_ts = c_es = c_ts = 0
+    if z_actor is not None:
+        za, T, a_es, a_ts = _nbr_view(z_actor)
+        assert adj is not None and adj.dtype == torch.float32 and adj.shape[-2:] == (P, P) and adj.numel() == R * P * P and _rows_ok(adj.reshape(R, P, P))
+    if z_critic is not None:
+        zc, Tc, c_es, c_ts = _nbr_view(z_critic)
+        assert z_actor is None or Tc == T
+        T = Tc
+    o_a = (out[0] if both else out) if z_actor is not None else None
+    o_c = (out[1] if both else out) if z_critic is not None else None
+    adj3 = adj.reshape(R, P, P) if adj is not None else None
+    _check(L.fcra_neighbour_mean(R, P, E, T, _ptr(za), a_es, a_ts, _ptr(zc), c_es, c_ts, _ptr(adj3), adj3.stride(0) if adj3 is not None else 0,
+                                 _ptr(bias.detach() if bias is not None else None), int(bool(relu)), _ptr(o_a), _ptr(o_c), _stream()),
+           "fcra_neighbour_mean")
     return out
 
 

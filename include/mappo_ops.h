@@ -213,6 +213,19 @@ int64_t wgrad_tn_workspace(int32_t M, int32_t N);
 int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
              void *workspace, void *stream);
 /*
+ * Neighbour mean of DHGN.fcra (DHGN/mappo_parallel.py:204-233: `torch.matmul(F.normalize(adj, p=1, dim=-1), hist)`), R rows of P
+ * agents and E features:  out[r][i][:] = act( sum_j abar[r][i][j] z[r][j][:] + bias ),  act = ReLU when relu != 0.
+ *   actor (out_actor != NULL): abar = adj / max(sum_j |adj|, 1e-12), adj [R][P][P] (adj_row_stride elements between rows);
+ *   critic (out_critic != NULL): abar = 1 / P (the normalised ones_like(adj) of AttributeDataset :64-65).
+ * z_* are read in place from a (N, T', P, E) history buffer: row r = (n, t) = (r / T, r % T) starts at n * episode_stride +
+ * t * step_stride (T = 1 and episode_stride = P E: a dense [R][P][E] tensor); bias [E] or NULL; out_* dense [R][P][E].
+ * Either output may be NULL; both together serve the rollout's paired actor / critic tick.
+ */
+int fcra_neighbour_mean(int32_t R, int32_t P, int32_t E, int32_t T, const float *z_actor, int64_t za_episode_stride, int64_t za_step_stride,
+                        const float *z_critic, int64_t zc_episode_stride, int64_t zc_step_stride, const float *adj, int64_t adj_row_stride,
+                        const float *bias, int32_t relu, float *out_actor, float *out_critic, void *stream);
+
+/*
  * ReLU backward and the bias gradient of the Linear in front of it in one pass (autograd: aten::threshold_backward, then
  * grad.sum(0) re-reading it; MAPPO.train's loss.backward(), DHGN/mappo_parallel.py:660-708):
  *   gin [R][F] = gout * [y > 0] (y = the saved ReLU output);  colsum [F] = sum_r gin[r][:].

@@ -526,3 +526,33 @@ def test_relu_backward_with_bias_gradient_matches_torch(R, F):
         ref += want[s0:s0 + 262144].double().sum(0)
     assert (cs.double() - ref).abs().max().item() < 2e-5 * float(R) ** 0.5
     assert torch.equal(ops.relu_bwd_colsum(gout, y)[1], cs)
+
+
+@pytest.mark.parametrize("P,T,relu", [(8, 1, False), (8, 7, True), (4, 5, False), (15, 3, True)])
+def test_fcra_neighbour_mean_matches_torch(P, T, relu):
+    """fcra_mean (DHGN.fcra's matmul(normalize(adj, p=1), hist), actor and critic weights, optional bias + ReLU, strided history
+    slices read in place) against the torch ops in float64."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(P * 10 + T)
+    n, E, d = 6, 128, 2
+    R = n * T
+    buf = torch.randn(n, T + d, P, E, device="cuda")
+    z = buf[:, 1:1 + T]                                             # (n, T, P, E) slice, not contiguous
+    adj = (torch.rand(R, P, P, device="cuda") < 0.4).float()
+    adj[0] = 0.0                                                    # isolated agents: normalize(0) = 0
+    adj[1] = torch.rand(P, P, device="cuda") - 0.3                  # general (signed) weights
+    bias = torch.randn(E, device="cuda") if relu else None
+    z64 = z.reshape(R, P, E).double()
+
+    def ref(a):
+        y = torch.matmul(torch.nn.functional.normalize(a.double(), p=1, dim=-1), z64)
+        if bias is not None:
+            y = y + bias.double()
+        return torch.relu(y) if relu else y
+    got_a = ops.fcra_mean(z_actor=z if T > 1 else z.reshape(R, P, E).contiguous(), adj=adj, bias=bias, relu=relu)
+    got_c = ops.fcra_mean(z_critic=z if T > 1 else z.reshape(R, P, E).contiguous(), bias=bias, relu=relu)
+    both = ops.fcra_mean(z_actor=z if T > 1 else z.reshape(R, P, E).contiguous(), z_critic=z if T > 1 else z.reshape(R, P, E).contiguous(),
+                         adj=adj, bias=bias, relu=relu)
+    assert torch.allclose(got_a.double(), ref(adj), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(got_c.double(), ref(torch.ones_like(adj)), rtol=1e-5, atol=1e-5)
+    assert torch.equal(both[0], got_a) and torch.equal(both[1], got_c)
