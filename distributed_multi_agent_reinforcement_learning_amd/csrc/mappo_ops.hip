@@ -812,8 +812,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int gru_hidx(int row, int k) { return ((k & 3) * GRU_RB + row) * GRU_LD + (k >> 2); }
 
+// gi_agents: row order of gi (and of dgi in the backward kernel).  0: time-major [t][b] like out.  P > 0: the rows of the
+// encoder's output, (episode n, step t, agent p) with b = n P + p, i.e. row ((b / P) T + t) P + b % P -- the input projection
+// and its gradients then run on the embedding as it lies in memory, and the two permuted copies of the (rows, 128) sequence
+// tensors autograd would make around the GRU (reference _sequence_features, DHGN/mappo_parallel.py:426-437) do not exist.
+__device__ __forceinline__ size_t gru_gi_row(int b, int t, int T, int B, int gi_agents) {
+    return gi_agents ? ((size_t)(b / gi_agents) * T + t) * gi_agents + b % gi_agents : (size_t)t * B + b;
+}
+
 __global__ __launch_bounds__(512) void k_gru_seq_fwd(int T, int B, const float *gi, const float *w_hh, const float *b_hh, const float *h0,
-                                                     float *out, float *save) {
+                                                     float *out, float *save, int gi_agents) {
     __shared__ __attribute__((aligned(16))) float hs[2][4 * GRU_RB * GRU_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int b0 = blockIdx.x * GRU_RB;
@@ -841,7 +849,7 @@ __global__ __launch_bounds__(512) void k_gru_seq_fwd(int T, int B, const float *
             const int row = 4 * q + reg;
             gir[reg] = giz[reg] = gin[reg] = 0.f;
             if (b0 + row < B) {
-                const float *g = gi + ((size_t)t * B + b0 + row) * 3 * GRU_H;
+                const float *g = gi + gru_gi_row(b0 + row, t, T, B, gi_agents) * 3 * GRU_H;
                 gir[reg] = g[j]; giz[reg] = g[GRU_H + j]; gin[reg] = g[2 * GRU_H + j];
             }
         }
@@ -1011,7 +1019,7 @@ constexpr int GRU_LD3 = 100;  // 96 k-groups + 4 pad
 __device__ __forceinline__ int gru_gidx(int row, int k) { return ((k & 3) * GRU_RB + row) * GRU_LD3 + (k >> 2); }
 
 __global__ __launch_bounds__(512) void k_gru_seq_bwd(int T, int B, const float *dout, const float *save, const float *out, const float *h0,
-                                                     const float *w_hh, float *dgi, float *dgh, float *dh0, float *bias_partials) {
+                                                     const float *w_hh, float *dgi, float *dgh, float *dh0, float *bias_partials, int gi_agents) {
     __shared__ __attribute__((aligned(16))) float gs[4 * GRU_RB * GRU_LD3];
     float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;  // column sums of dgi / dgh over this workgroup's rows and all steps
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -1060,8 +1068,8 @@ __global__ __launch_bounds__(512) void k_gru_seq_bwd(int T, int B, const float *
                 dr = dn * hn * r * (1.f - r);
                 dnr = dn * r;
                 dhz[reg] = dh * z;
-                const size_t g = ((size_t)t * B + b0 + row) * 3 * GRU_H;
-                dgi[g + j] = dr; dgi[g + GRU_H + j] = dz; dgi[g + 2 * GRU_H + j] = dn;
+                const size_t g = ((size_t)t * B + b0 + row) * 3 * GRU_H, gq = gru_gi_row(b0 + row, t, T, B, gi_agents) * 3 * GRU_H;
+                dgi[gq + j] = dr; dgi[gq + GRU_H + j] = dz; dgi[gq + 2 * GRU_H + j] = dn;
                 dgh[g + j] = dr; dgh[g + GRU_H + j] = dz; dgh[g + 2 * GRU_H + j] = dnr;
                 sb_r += dr; sb_z += dz; sb_n += dn; sb_nr += dnr;
             }
@@ -1785,21 +1793,22 @@ int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, cons
 }
 
 int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
-                float *save, void *stream) {
-    if (T < 1 || B < 1 || H != GRU_H || !gi || !w_hh || !b_hh || !h0 || !out) return MO_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k_gru_seq_fwd, dim3((B + GRU_RB - 1) / GRU_RB), dim3(512), 0, (hipStream_t)stream, T, B, gi, w_hh, b_hh, h0, out, save);
+                float *save, int32_t gi_agents, void *stream) {
+    if (T < 1 || B < 1 || H != GRU_H || !gi || !w_hh || !b_hh || !h0 || !out || gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_gru_seq_fwd, dim3((B + GRU_RB - 1) / GRU_RB), dim3(512), 0, (hipStream_t)stream, T, B, gi, w_hh, b_hh, h0, out, save, (int)gi_agents);
     return (int)hipGetLastError();
 }
 
 int64_t gru_seq_bwd_workspace(int32_t B) { return (int64_t)((B + GRU_RB - 1) / GRU_RB) * 4 * GRU_H * sizeof(float); }
 
 int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0, const float *w_hh,
-                float *dgi, float *dgh, float *dh0, float *db_ih, float *db_hh, void *workspace, void *stream) {
+                float *dgi, float *dgh, float *dh0, float *db_ih, float *db_hh, int32_t gi_agents, void *workspace, void *stream) {
     if (T < 1 || B < 1 || H != GRU_H || !dout || !save || !out || !h0 || !w_hh || !dgi || !dgh || !dh0) return MO_ERR_BAD_ARG;
+    if (gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
     if ((db_ih || db_hh) && (!db_ih || !db_hh || !workspace)) return MO_ERR_BAD_ARG;
     const int nblk = (B + GRU_RB - 1) / GRU_RB;
     hipLaunchKernelGGL(k_gru_seq_bwd, dim3(nblk), dim3(512), 0, (hipStream_t)stream, T, B, dout, save, out, h0, w_hh, dgi, dgh, dh0,
-                       db_ih ? (float *)workspace : (float *)nullptr);
+                       db_ih ? (float *)workspace : (float *)nullptr, (int)gi_agents);
     if (db_ih)
         hipLaunchKernelGGL(k_gru_bias_reduce, dim3(4 * GRU_H / 4), dim3(256), 0, (hipStream_t)stream, nblk, (const float *)workspace, db_ih, db_hh);
     return (int)hipGetLastError();

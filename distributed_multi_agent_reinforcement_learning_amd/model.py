@@ -168,11 +168,13 @@ class _Trunk(nn.Module):
         return feat.reshape(R, P, self.rnn_hidden_dim), hidden_state
 
     def _sequence_features(self, embedding, batch, steps):
+        """embedding: (batch steps, P, E) rows in (episode, step) order -> GRU features TIME-MAJOR (steps, batch, P, H).  The
+        reference permutes the embedding to (steps, batch P, E) and the features back (:426-437); here the first GRU layer
+        reads the rows where they lie and the (small) head outputs are permuted instead of the features."""
         P = embedding.shape[1]
-        x = embedding.reshape(batch, steps, P, self.rnn_input_dim).permute(1, 0, 2, 3).reshape(steps, batch * P, self.rnn_input_dim)
-        h0 = torch.zeros(self.num_layers, batch * P, self.rnn_hidden_dim, dtype=x.dtype, device=x.device)
-        feat, _ = ops.gru(x.contiguous(), h0, self.GRU)
-        return feat.reshape(steps, batch, P, self.rnn_hidden_dim).permute(1, 0, 2, 3)
+        h0 = torch.zeros(self.num_layers, batch * P, self.rnn_hidden_dim, dtype=embedding.dtype, device=embedding.device)
+        feat, _ = ops.gru(embedding.reshape(batch * steps * P, self.rnn_input_dim), h0, self.GRU, agents=P, steps=steps)
+        return feat.reshape(steps, batch, P, self.rnn_hidden_dim)
 
     def head(self, feat):
         """the output layer on GRU features.  A spectrally normalised head (the critic's, :485) outside autograd takes its
@@ -220,10 +222,10 @@ class SharedActor(_Trunk):
                               False, None, obs.get("q_div", 1), emb_out)
         if mode == 0:
             feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)
-        else:
-            feat, hidden_state = self._sequence_features(emb, batch, steps), None
-        prob = torch.softmax(self.Mean(feat), dim=-1)
-        return prob, hidden_state, emb
+            return torch.softmax(self.Mean(feat), dim=-1), hidden_state, emb
+        feat = self._sequence_features(emb, batch, steps)                       # (steps, batch, P, H)
+        prob = torch.softmax(self.Mean(feat), dim=-1).permute(1, 0, 2, 3)       # the (.., A) result is what gets permuted
+        return prob, None, emb
 
     def get_logprob_and_entropy(self, obs, hist, action, batch, steps):
         """Categorical(prob).log_prob / entropy (:451-456)"""
@@ -251,8 +253,8 @@ class SharedCritic(_Trunk):
         if mode == 0:
             feat, hidden_state = self._rollout_features(emb, hidden_state, inplace_hidden)
             return self.head(feat), hidden_state, emb
-        feat = self._sequence_features(emb, batch, steps)
-        return self.Mean(feat)
+        feat = self._sequence_features(emb, batch, steps)                       # (steps, batch, P, H)
+        return self.Mean(feat).permute(1, 0, 2, 3)
 
 
 def build_actor_critic(cfg, device):

@@ -52,8 +52,8 @@ def load_library():
         L.gru_gates_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.gru_gates_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_cell_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
-        L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-        L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
+        L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         L.gru_seq_bwd_workspace.argtypes = [i32]
         L.gru_seq_bwd_workspace.restype = i64
         L.wgrad_tn_workspace.argtypes = [i32, i32]
@@ -696,31 +696,42 @@ PERSISTENT_GRU_MIN_T = 2  # sequences at least this long take the one-launch rec
 
 
 class _GRULayer(torch.autograd.Function):
-    """One torch.nn.GRU layer over a sequence: the input projection and the recurrent projection are fp32 MFMA GEMMs
-    (rocBLAS / hipBLASLt), the gate math between them is the fused HIP kernel pair gru_gates_{fwd,bwd}."""
+    """One torch.nn.GRU layer over a sequence: the input projection is one fp32 MFMA GEMM (rocBLAS / hipBLASLt), the
+    recurrence runs in the persistent kernel pair gru_seq_{fwd,bwd} (or, for short sequences / other sizes, a GEMM and the
+    gate kernels per step).  x: (T, B, I) time-major, or -- agents = P > 0 -- the (T B, I) rows of the encoder's output in
+    (episode, step, agent) order (sequence b = n P + p): the projection and its gradients then use the embedding as it lies
+    in memory (no permuted copy on the way in, none for the gradient on the way out).  out: (T, B, H) time-major."""
 
     @staticmethod
-    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh, T, B, agents):
         L = load_library()
         _need_gpu(x, "gru")
-        T, B, I = x.shape
+        I = x.shape[-1]
         H = w_hh.shape[1]
+        persistent = bool(H == 128 and T >= PERSISTENT_GRU_MIN_T)
+        ctx.x_shape = x.shape
+        ctx.ungather = 0
+        if agents and not persistent:  # the per-step path is time-major only: gather the rows once
+            x = x.reshape(B // agents, T, agents, I).permute(1, 0, 2, 3).reshape(T, B, I)
+            ctx.ungather = int(agents)
+            agents = 0
         x = x.contiguous()
         h0 = h0.contiguous()
         need = any(ctx.needs_input_grad)
         out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
-        gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t()).reshape(T, B, 3 * H)
+        gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())
         save = torch.empty((T, 4, B, H), dtype=x.dtype, device=x.device) if need else None
         b_hh = b_hh.contiguous()
         st = _stream()
-        ctx.persistent = bool(H == 128 and T >= PERSISTENT_GRU_MIN_T)
-        if ctx.persistent:  # whole recurrence in one launch, W_hh in registers (csrc/mappo_ops.hip k_gru_seq_fwd)
+        ctx.persistent, ctx.dims, ctx.agents = persistent, (T, B, I), int(agents)
+        if persistent:  # whole recurrence in one launch, W_hh in registers (csrc/mappo_ops.hip k_gru_seq_fwd)
             whh = w_hh.detach().contiguous()
-            _check(L.gru_seq_fwd(T, B, H, _ptr(gi), _ptr(whh), _ptr(b_hh), _ptr(h0), _ptr(out), _ptr(save) if need else None, st),
+            _check(L.gru_seq_fwd(T, B, H, _ptr(gi), _ptr(whh), _ptr(b_hh), _ptr(h0), _ptr(out), _ptr(save) if need else None, int(agents), st),
                    "gru_seq_fwd")
             if need:
                 ctx.save_for_backward(x, h0, w_ih, whh, out, save)
             return out
+        gi = gi.reshape(T, B, 3 * H)
         gh = torch.empty((B, 3 * H), dtype=x.dtype, device=x.device)
         w_hh_t = w_hh.t()
         hprev = h0
@@ -737,10 +748,10 @@ class _GRULayer(torch.autograd.Function):
     def backward(ctx, dout):
         L = load_library()
         x, h0, w_ih, w_hh, out, save = ctx.saved_tensors
-        T, B, I = x.shape
+        T, B, I = ctx.dims
         H = w_hh.shape[1]
         dout = dout.contiguous()
-        dgi = torch.empty((T, B, 3 * H), dtype=x.dtype, device=x.device)
+        dgi = torch.empty((T * B, 3 * H), dtype=x.dtype, device=x.device)   # rows in x's order
         dgh = torch.empty((T, B, 3 * H), dtype=x.dtype, device=x.device)
         dh_direct = torch.empty((B, H), dtype=x.dtype, device=x.device)
         dcarry = None
@@ -751,33 +762,47 @@ class _GRULayer(torch.autograd.Function):
             db_hh = torch.empty(3 * H, dtype=x.dtype, device=x.device)
             ws = torch.empty(L.gru_seq_bwd_workspace(B), dtype=torch.uint8, device=x.device)
             _check(L.gru_seq_bwd(T, B, H, _ptr(dout), _ptr(save), _ptr(out), _ptr(h0), _ptr(w_hh), _ptr(dgi), _ptr(dgh), _ptr(dh_direct),
-                                 _ptr(db_ih), _ptr(db_hh), _ptr(ws), st), "gru_seq_bwd")
+                                 _ptr(db_ih), _ptr(db_hh), ctx.agents, _ptr(ws), st), "gru_seq_bwd")
             dcarry = dh_direct
         else:
+            dgi3 = dgi.view(T, B, 3 * H)
             for t in range(T - 1, -1, -1):
                 hprev = out[t - 1] if t > 0 else h0
-                _check(L.gru_gates_bwd(B, H, _ptr(dout[t]), _ptr(dcarry), _ptr(save[t]), _ptr(hprev), _ptr(dgi[t]), _ptr(dgh[t]),
+                _check(L.gru_gates_bwd(B, H, _ptr(dout[t]), _ptr(dcarry), _ptr(save[t]), _ptr(hprev), _ptr(dgi3[t]), _ptr(dgh[t]),
                                        _ptr(dh_direct), st), "gru_gates_bwd")
                 dcarry = torch.addmm(dh_direct, dgh[t], w_hh)
-        dgi2, dgh2 = dgi.reshape(T * B, 3 * H), dgh.reshape(T * B, 3 * H)
+        dgh2 = dgh.reshape(T * B, 3 * H)
         dw_hh = torch.mm(dgh[0].t(), h0)
         if T > 1:
             wgrad(dgh[1:].reshape((T - 1) * B, 3 * H), out[:-1].reshape((T - 1) * B, H), out=dw_hh, accumulate=True)
-        dw_ih = wgrad(dgi2, x.reshape(T * B, I))
-        dx = torch.mm(dgi2, w_ih).reshape(T, B, I) if ctx.needs_input_grad[0] else None
+        x2 = x.reshape(T * B, I)
+        dw_ih = wgrad(dgi, x2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dgi, w_ih)
+            if ctx.ungather:   # back to the caller's (episode, step, agent) rows
+                P = ctx.ungather
+                dx = dx.reshape(T, B // P, P, I).permute(1, 0, 2, 3)
+            dx = dx.reshape(ctx.x_shape)
         if db_ih is None:
-            db_ih, db_hh = dgi2.sum(0), dgh2.sum(0)
-        return dx, dcarry, dw_ih, dw_hh, db_ih, db_hh
+            db_ih, db_hh = dgi.sum(0), dgh2.sum(0)
+        return dx, dcarry, dw_ih, dw_hh, db_ih, db_hh, None, None, None
 
 
-def gru(x, h0, gru_module, inplace_hidden=False):
+def gru(x, h0, gru_module, inplace_hidden=False, agents=0, steps=None):
     """torch.nn.GRU(x, h0) semantics (seq-first, unidirectional, no dropout) on the fused path.
     x (T, B, I), h0 (num_layers, B, H) -> out (T, B, H), h_n (num_layers, B, H).
+    agents = P > 0: x is instead the (B T, I) rows of the encoder's output in (episode, step, agent) order with T = steps
+    (sequence b = n P + p); the first layer reads them in place (see _GRULayer), the result is time-major all the same.
     inplace_hidden (single rollout step only): the new hidden state overwrites h0 (each 16-row tile is read before it is
     written by the one workgroup that owns it) and h_n IS h0 -- no stack, no copy back into the rollout state."""
     hn = []
     inp = x
-    T, B = x.shape[0], x.shape[1]
+    if agents:
+        assert x.dim() == 2 and steps and x.shape[0] % (steps * agents) == 0
+        T, B = int(steps), x.shape[0] // int(steps)
+    else:
+        T, B = x.shape[0], x.shape[1]
     for layer in range(gru_module.num_layers):
         w_ih, w_hh = getattr(gru_module, f"weight_ih_l{layer}"), getattr(gru_module, f"weight_hh_l{layer}")
         b_ih, b_hh = getattr(gru_module, f"bias_ih_l{layer}"), getattr(gru_module, f"bias_hh_l{layer}")
@@ -791,7 +816,7 @@ def gru(x, h0, gru_module, inplace_hidden=False):
                                                _ptr(b_hh.detach().contiguous()), _ptr(out), _stream()), "gru_cell_fwd")
             inp = out
         else:
-            inp = _GRULayer.apply(inp, h0[layer], w_ih, w_hh, b_ih, b_hh)
+            inp = _GRULayer.apply(inp, h0[layer], w_ih, w_hh, b_ih, b_hh, T, B, int(agents) if layer == 0 else 0)
         hn.append(inp[-1])
     if all(t.data_ptr() == h0[k].data_ptr() for k, t in enumerate(hn)):
         return inp, h0

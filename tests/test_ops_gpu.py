@@ -556,3 +556,31 @@ def test_fcra_neighbour_mean_matches_torch(P, T, relu):
     assert torch.allclose(got_a.double(), ref(adj), rtol=1e-5, atol=1e-5)
     assert torch.allclose(got_c.double(), ref(torch.ones_like(adj)), rtol=1e-5, atol=1e-5)
     assert torch.equal(both[0], got_a) and torch.equal(both[1], got_c)
+
+
+@pytest.mark.parametrize("T,n,P", [(37, 20, 8), (150, 7, 4), (5, 6, 8)])
+def test_gru_reads_encoder_row_order_in_place(T, n, P):
+    """ops.gru(agents = P): the first layer's input given as the encoder's (episode, step, agent) rows equals the time-major
+    call on the permuted copy -- outputs bit for bit, gradients to fp32 reordering (T = 5 takes the per-step path, which
+    gathers once)."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(T + n)
+    B, E = n * P, 128
+    g = torch.nn.GRU(E, E, 2).cuda()
+    emb = torch.randn(n * T * P, E, device="cuda")
+    h0 = torch.zeros(2, B, E, device="cuda")
+    gout = torch.randn(T, B, E, device="cuda")
+    res = []
+    for agents in (0, P):
+        x = emb.clone().requires_grad_(True)
+        g.zero_grad()
+        if agents:
+            out, _ = ops.gru(x, h0, g, agents=P, steps=T)
+        else:
+            out, _ = ops.gru(x.reshape(n, T, P, E).permute(1, 0, 2, 3).reshape(T, B, E), h0, g)
+        (out * gout).sum().backward()
+        res.append((out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in g.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * a.abs().max().item())

@@ -21,7 +21,7 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-tf = timeit(lambda: L.gru_seq_fwd(T, B, H, ptr(gi), ptr(w), ptr(b), ptr(h0), ptr(out), ptr(save), st))
-tb = timeit(lambda: L.gru_seq_bwd(T, B, H, ptr(dout), ptr(save), ptr(out), ptr(h0), ptr(w), ptr(dgi), ptr(dgh), ptr(dh0), ptr(dbi), ptr(dbh), ptr(ws), st))
+tf = timeit(lambda: L.gru_seq_fwd(T, B, H, ptr(gi), ptr(w), ptr(b), ptr(h0), ptr(out), ptr(save), 0, st))
+tb = timeit(lambda: L.gru_seq_bwd(T, B, H, ptr(dout), ptr(save), ptr(out), ptr(h0), ptr(w), ptr(dgi), ptr(dgh), ptr(dh0), ptr(dbi), ptr(dbh), 0, ptr(ws), st))
 fl = 2.0 * T * B * H * 3 * H
 print(f"gru_seq_fwd {tf:.1f} us ({fl/tf/1e6:.1f} TFLOP/s, {tf/T:.2f} us/step)   gru_seq_bwd {tb:.1f} us ({fl/tb/1e6:.1f} TFLOP/s, {tb/T:.2f} us/step)")
