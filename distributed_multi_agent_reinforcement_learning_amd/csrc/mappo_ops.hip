@@ -732,6 +732,137 @@ __global__ void k_categorical(int R, int A, const float *probs, uint64_t seed, u
 }
 
 
+// LDS hand-over between the lanes of ONE wave (no workgroup barrier): order the stores before the loads
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over each row of 16 lanes, result in all 16 (DPP only: quad butterflies, then the half-row and row mirrors)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror: the other quad of the half
+    v += dpp_f<0x140>(v);  // row_mirror: the other half
+    return v;
+}
+
+// ---- output heads of the rollout tick ------------------------------------------------------------------------------------------
+// y[r][a] = feat[r] . W[a] + b[a] for a head with A <= 16 outputs on H = 128 features.  Sixteen lanes share a row (lane i holds
+// features 8 i .. 8 i + 7 and the matching weight columns in registers; the A dot products are folded with four xor-shuffles), a
+// wave covers 64 rows in 16 such steps and parks the logits in LDS, then every lane finishes ONE row on its own:
+//   SAMPLE: the actor -- softmax, Categorical sample and log-probability as in k_categorical: one launch instead of GEMM +
+//           softmax + sample + counter update (the counter is advanced by the last workgroup out).
+//   else  : the critic -- y written out (A = 1: the value), straight into the rollout's static storage.
+constexpr int HEAD_MAX_A = 16, HEAD_H = 128;
+template <bool SAMPLE, int AT>
+__global__ __launch_bounds__(256) void k_head(int R, int A, const float *__restrict__ feat, const float *__restrict__ W, const float *__restrict__ b,
+                                              float *__restrict__ y, uint64_t seed, uint64_t *counter, unsigned int *done, int greedy,
+                                              int32_t *__restrict__ action, float *__restrict__ logp) {
+    __shared__ float s_y[4][64][AT + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    float w[AT][8];
+#pragma unroll
+    for (int a = 0; a < AT; a++)   // (A == AT: the host picks the instantiation)
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[a][k] = W[a * HEAD_H + 8 * i + k];
+    const uint64_t offset = SAMPLE ? *counter : 0ull;
+    float (*sy)[AT + 1] = s_y[wave];
+    for (int r0 = (blockIdx.x * 4 + wave) * 64; r0 < R; r0 += nw * 64) {
+        float4 fall[16][2];  // all 64 rows' loads in flight before the first use (one memory latency per 64 rows, not sixteen)
+#pragma unroll
+        for (int st = 0; st < 16; st++) {
+            const int r = r0 + 4 * st + g;
+            fall[st][0] = fall[st][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R) {
+                fall[st][0] = *(const float4 *)(feat + (size_t)r * HEAD_H + 8 * i);
+                fall[st][1] = *(const float4 *)(feat + (size_t)r * HEAD_H + 8 * i + 4);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 16; st++) {
+            const int row = 4 * st + g;
+            const float4 fa = fall[st][0], fb = fall[st][1];
+            float mine = 0.f;
+#pragma unroll
+            for (int a = 0; a < AT; a++) {
+                float sum = fa.x * w[a][0];
+                sum = __builtin_fmaf(fa.y, w[a][1], sum); sum = __builtin_fmaf(fa.z, w[a][2], sum); sum = __builtin_fmaf(fa.w, w[a][3], sum);
+                sum = __builtin_fmaf(fb.x, w[a][4], sum); sum = __builtin_fmaf(fb.y, w[a][5], sum); sum = __builtin_fmaf(fb.z, w[a][6], sum);
+                sum = __builtin_fmaf(fb.w, w[a][7], sum);
+                sum = row16_sum(sum);
+                mine = i == a ? sum : mine;   // lane a of the group keeps output a
+            }
+            if (i < AT) sy[row][i] = mine;
+        }
+        wave_fence();  // the 64 rows' logits are in LDS: lane l takes row l
+        const int r = r0 + lane;
+        if (r < R) {
+            float v[AT];
+#pragma unroll
+            for (int a = 0; a < AT; a++) v[a] = sy[lane][a] + b[a];
+            if (!SAMPLE) {
+#pragma unroll
+                for (int a = 0; a < AT; a++) y[(size_t)r * AT + a] = v[a];
+            } else {
+                // softmax over the A logits (max-subtracted, as torch.softmax), then k_categorical's sampling on the probabilities
+                float mx = v[0];
+#pragma unroll
+                for (int a = 1; a < AT; a++) mx = fmaxf(mx, v[a]);
+                float p[AT], den = 0.f;
+#pragma unroll
+                for (int a = 0; a < AT; a++) { p[a] = expf(v[a] - mx); den += p[a]; }
+                float tot = 0.f;
+#pragma unroll
+                for (int a = 0; a < AT; a++) { p[a] = p[a] / den; tot += p[a]; }
+                int act = 0;
+                float pa = p[0];
+                if (greedy) {
+#pragma unroll
+                    for (int a = 1; a < AT; a++) { const bool up = p[a] > pa; pa = up ? p[a] : pa; act = up ? a : act; }
+                } else {
+                    uint32_t o[4];
+                    const uint64_t ctr = offset + (uint64_t)r;
+                    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+                    const float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f) * tot;  // (0, tot)
+                    float cum = 0.f;
+                    bool found = false;
+                    act = AT - 1;
+                    pa = p[AT - 1];
+#pragma unroll
+                    for (int a = 0; a < AT; a++) {
+                        cum += p[a];
+                        const bool hit = !found && u < cum;
+                        act = hit ? a : act;
+                        pa = hit ? p[a] : pa;
+                        found = found || hit;
+                    }
+                }
+                action[r] = act;
+                float pn = pa / tot;
+                pn = fminf(fmaxf(pn, 1.1920929e-07f), 1.f - 1.1920929e-07f);
+                logp[r] = logf(pn);
+            }
+        }
+        wave_fence();  // before the next 64 rows overwrite the logits
+    }
+    if (SAMPLE) {  // every workgroup has read the counter at its start; the last one to finish advances it and resets the ticket
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(done, 1u) == gridDim.x - 1) {
+                *counter = offset + (uint64_t)R;
+                *done = 0u;
+                __threadfence();
+            }
+        }
+    }
+}
+
 // ---- GRU gate math (torch.nn.GRU cell; reference DHGN/mappo_parallel.py:397,424,434) ------------------------------
 // gi = x W_ih^T + b_ih and gh = h W_hh^T come from MFMA GEMMs (rocBLAS/hipBLASLt fp32); everything between them and
 // the next step's GEMM is fused here: bias, sigmoid/tanh, the state update and (for training) the saved gates.
@@ -1760,6 +1891,38 @@ int spectral_norm_weight(int32_t A, int32_t H, const float *W, float *u, float *
                          void *stream) {
     if (A < 1 || A > SN_MAX_A || H < 1 || H > SN_MAX_H || !W || !u || !v || !w_eff || n_power_iterations < 0) return MO_ERR_BAD_ARG;
     hipLaunchKernelGGL(k_sn_power, dim3(1), dim3(256), 0, (hipStream_t)stream, A, H, W, u, v, eps, n_power_iterations, w_eff);
+    return (int)hipGetLastError();
+}
+
+int head_grid(int R) { const int g = (R + 255) / 256; return g < 1024 ? g : 1024; }  // 4 waves x 64 rows per workgroup step
+
+int head_linear(int32_t R, int32_t A, int32_t H, const float *feat, const float *W, const float *b, float *y, void *stream) {
+    if (R < 0 || A < 1 || A > HEAD_MAX_A || H != HEAD_H || !feat || !W || !b || !y || ((uintptr_t)feat & 15)) return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+#define HEAD_LIN(AT) case AT: hipLaunchKernelGGL((k_head<false, AT>), dim3(head_grid(R)), dim3(256), 0, st, R, A, feat, W, b, y, (uint64_t)0, \
+                                       (uint64_t *)nullptr, (unsigned int *)nullptr, 0, (int32_t *)nullptr, (float *)nullptr); break;
+    switch (A) {
+        HEAD_LIN(1) HEAD_LIN(2) HEAD_LIN(3) HEAD_LIN(4) HEAD_LIN(5) HEAD_LIN(6) HEAD_LIN(7) HEAD_LIN(8) HEAD_LIN(9) HEAD_LIN(10) HEAD_LIN(11)
+        HEAD_LIN(12) HEAD_LIN(13) HEAD_LIN(14) HEAD_LIN(15) HEAD_LIN(16)
+    }
+#undef HEAD_LIN
+    return (int)hipGetLastError();
+}
+
+int head_sample(int32_t R, int32_t A, int32_t H, const float *feat, const float *W, const float *b, uint64_t seed, uint64_t *counter,
+                uint32_t *ticket, int32_t greedy, int32_t *action, float *logp, void *stream) {
+    if (R < 0 || A < 1 || A > HEAD_MAX_A || H != HEAD_H || !feat || !W || !b || !counter || !ticket || !action || !logp || ((uintptr_t)feat & 15))
+        return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+#define HEAD_SMP(AT) case AT: hipLaunchKernelGGL((k_head<true, AT>), dim3(head_grid(R)), dim3(256), 0, st, R, A, feat, W, b, (float *)nullptr, seed, \
+                                       counter, ticket, (int)greedy, action, logp); break;
+    switch (A) {
+        HEAD_SMP(1) HEAD_SMP(2) HEAD_SMP(3) HEAD_SMP(4) HEAD_SMP(5) HEAD_SMP(6) HEAD_SMP(7) HEAD_SMP(8) HEAD_SMP(9) HEAD_SMP(10) HEAD_SMP(11)
+        HEAD_SMP(12) HEAD_SMP(13) HEAD_SMP(14) HEAD_SMP(15) HEAD_SMP(16)
+    }
+#undef HEAD_SMP
     return (int)hipGetLastError();
 }
 

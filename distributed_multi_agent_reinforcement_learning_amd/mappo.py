@@ -263,9 +263,10 @@ class MAPPO:
                 st.replay_policy_step()
             else:
                 st.policy_step()
-            items += [(st.a_cur, buf["actor_historical_embedding"][rows, t + d]), (st.c_cur, buf["critic_historical_embedding"][rows, t + d]),
-                      (st.v, buf["v_n"][rows, t]), (st.a_n, buf["a_n"][rows, t]),      # int32 -> float32 like the reference buffer
+            items += [(st.v, buf["v_n"][rows, t]), (st.a_n, buf["a_n"][rows, t]),      # int32 -> float32 like the reference buffer
                       (st.logp, buf["a_logprob_n"][rows, t])]
+            if d:  # the update reads the stored embeddings as FCRA history only (EmbeddingDataset2, :95-113): nothing to keep at depth 0
+                items += [(st.a_cur, buf["actor_historical_embedding"][rows, t + d]), (st.c_cur, buf["critic_historical_embedding"][rows, t + d])]
             # one launch records the tick (and adds the previous tick's raw reward to the episode return)
             ops.rollout_record(items, raw if t > 0 else None, episode_reward)
             if t + 1 < T:
@@ -317,6 +318,7 @@ class _RolloutState:
         self.a_n = torch.zeros((N, P), dtype=torch.int32, device=dev)
         self.logp, self.v, self.raw = z(N, P), z(N, P), z(N, P)
         self.counter = torch.full((1,), int(agent.sample_rank) << 40, dtype=torch.int64, device=dev)  # position in the sampling stream (persists)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # scratch of ops.head_sample (left zero by every launch)
         self.graph = None
         # one encoder pass per tick for both networks (DHGN.forward_pair): they hold the same DHGN instance (:582-616)
         self.pair_forward = agent.actor.shared_net is agent.critic.shared_net
@@ -364,15 +366,21 @@ class _RolloutState:
             a_emb, c_emb = emb[0], emb[1]
             feat_a, ha = ag.actor._rollout_features(a_emb, self.ha, True)
             feat_c, hc = ag.critic._rollout_features(c_emb, self.hc, True)
-            prob = torch.softmax(ag.actor.head(feat_a), dim=-1)
-            v = ag.critic.head(feat_c)
+            v = ag.critic.head(feat_c, out=self.v)            # the value lands in the static storage
+            w_a = ag.actor.head_weight() if forced_actions is None else None
+            if w_a is not None and feat_a.shape[-1] == ops.HEAD_FEATURES and w_a.shape[0] <= ops.HEAD_MAX_OUT:
+                # action head, softmax, sample, log-probability and the stream counter in one launch
+                ops.head_sample(feat_a.contiguous(), w_a, ag.actor.Mean.bias, ag.sample_seed, self.counter, self.ticket, (self.a_n, self.logp))
+                prob = None
+            else:
+                prob = torch.softmax(ag.actor.head(feat_a), dim=-1)
         else:
             prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True, emb_out=self.a_cur)
             v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True, emb_out=self.c_cur)
         if forced_actions is not None:
             self.a_n.copy_(forced_actions.to(torch.int32))
             self.logp.copy_(torch.distributions.Categorical(probs=prob).log_prob(forced_actions))
-        else:
+        elif prob is not None:
             ops.categorical_sample(prob, ag.sample_seed, 0, counter=self.counter, out=(self.a_n, self.logp))
         if ha is not self.ha:
             self.ha.copy_(ha)
@@ -382,7 +390,8 @@ class _RolloutState:
             self.a_cur.copy_(a_emb)
         if c_emb.data_ptr() != self.c_cur.data_ptr():
             self.c_cur.copy_(c_emb)
-        self.v.copy_(v.reshape(self.N, self.P))
+        if v.data_ptr() != self.v.data_ptr():
+            self.v.copy_(v.reshape(self.N, self.P))
 
     def value_step(self):
         ag, d = self.agent, self.d

@@ -176,18 +176,29 @@ class _Trunk(nn.Module):
         feat, _ = ops.gru(embedding.reshape(batch * steps * P, self.rnn_input_dim), h0, self.GRU, agents=P, steps=steps)
         return feat.reshape(steps, batch, P, self.rnn_hidden_dim)
 
-    def head(self, feat):
-        """the output layer on GRU features.  A spectrally normalised head (the critic's, :485) outside autograd takes its
-        pre-forward hook -- power iteration on u, v in place, weight / sigma -- as one launch (ops.spectral_norm_weight)
-        instead of the hook's ~14; under autograd the module call (the hook differentiates through weight / sigma)."""
+    def head_weight(self):
+        """the output layer's effective weight outside autograd, or None when the module call is needed.  A spectrally normalised
+        head (the critic's, :485) takes its pre-forward hook -- power iteration on u, v in place, weight / sigma -- as one launch
+        (ops.spectral_norm_weight) instead of the hook's ~14; under autograd the module call (the hook differentiates through
+        weight / sigma)."""
         m = self.Mean
-        if not torch.is_grad_enabled() and feat.is_cuda:
-            for hook in m._forward_pre_hooks.values():
-                if isinstance(hook, SpectralNorm) and hook.name == "weight" and hook.dim == 0 and m.weight_orig.dim() == 2:
-                    w = ops.spectral_norm_weight(m.weight_orig, m.weight_u, m.weight_v, hook.eps,
-                                                 hook.n_power_iterations if m.training else 0)
-                    return F.linear(feat, w, m.bias)
-        return m(feat)
+        if torch.is_grad_enabled() or not m.bias.is_cuda:
+            return None
+        hooks = list(m._forward_pre_hooks.values())
+        if not hooks:
+            return m.weight
+        if len(hooks) == 1 and isinstance(hooks[0], SpectralNorm) and hooks[0].name == "weight" and hooks[0].dim == 0 and m.weight_orig.dim() == 2:
+            return ops.spectral_norm_weight(m.weight_orig, m.weight_u, m.weight_v, hooks[0].eps,
+                                            hooks[0].n_power_iterations if m.training else 0)
+        return None
+
+    def head(self, feat, out=None):
+        """the output layer on GRU features; out: dense storage written in place (rollout)."""
+        w = self.head_weight()
+        if w is None:
+            y = self.Mean(feat)
+            return y if out is None else out.copy_(y.reshape(out.shape))
+        return ops.head_linear(feat, w, self.Mean.bias, out=out)
 
     def get_weights(self):
         return {k: v.cpu() for k, v in self.state_dict().items()}

@@ -49,6 +49,8 @@ def load_library():
         L.gae_advnorm.argtypes = [i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
         L.categorical_sample.argtypes = [i32, i32, vp, C.c_uint64, C.c_uint64, i32, vp, vp, vp]
         L.categorical_sample_counter.argtypes = [i32, i32, vp, C.c_uint64, vp, i32, vp, vp, vp]
+        L.head_linear.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
+        L.head_sample.argtypes = [i32, i32, i32, vp, vp, vp, C.c_uint64, vp, vp, i32, vp, vp, vp]
         L.gru_gates_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.gru_gates_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_cell_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -395,6 +397,47 @@ def categorical_sample(probs, seed, offset, greedy=False, counter=None, out=None
         _check(L.categorical_sample(R, A, _ptr(pr), int(seed), int(offset), 1 if greedy else 0, _ptr(action), _ptr(logp), _stream()),
                "categorical_sample")
     return action.reshape(shape), logp.reshape(shape)
+
+
+HEAD_MAX_OUT, HEAD_FEATURES = 16, 128
+
+
+def _head_ok(feat, W, b):
+    return (feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous() and W.shape[1] == HEAD_FEATURES and feat.shape[-1] == HEAD_FEATURES
+            and W.shape[0] <= HEAD_MAX_OUT and b is not None and not torch.is_grad_enabled())
+
+
+def head_linear(feat, W, b, out=None):
+    """feat W^T + b of a head with <= 16 outputs on 128 features in one launch (rollout, no autograd); out: dense storage of
+    feat.shape[:-1] + (A,) elements, written in place.  Other shapes: F.linear."""
+    if not _head_ok(feat, W, b):
+        y = F.linear(feat, W, b)
+        return y if out is None else out.copy_(y.reshape(out.shape))
+    L = load_library()
+    A = W.shape[0]
+    R = feat.numel() // HEAD_FEATURES
+    if out is None:
+        out = torch.empty(feat.shape[:-1] + (A,), dtype=torch.float32, device=feat.device)
+    assert out.is_contiguous() and out.numel() == R * A and out.dtype == torch.float32
+    _check(L.head_linear(R, A, HEAD_FEATURES, _ptr(feat), _ptr(W.detach().contiguous()), _ptr(b.detach().contiguous()), _ptr(out), _stream()),
+           "head_linear")
+    return out
+
+
+def head_sample(feat, W, b, seed, counter, ticket, out, greedy=False):
+    """Categorical(softmax(feat W^T + b)).sample() and its log-probability (argmax when greedy) for an action head with <= 16
+    outputs on 128 features in one launch; the stream position `counter` (int64, one element) advances by the number of rows
+    (replayable in a captured graph).  ticket: a zero uint32 tensor of one element.  out = (action int32, logp float32)."""
+    assert _head_ok(feat, W, b)
+    L = load_library()
+    action, logp = out
+    R = feat.numel() // HEAD_FEATURES
+    assert action.dtype == torch.int32 and logp.dtype == torch.float32 and action.is_contiguous() and logp.is_contiguous()
+    assert action.numel() == R and logp.numel() == R and counter.dtype == torch.int64 and counter.numel() == 1
+    assert ticket.dtype == torch.int32 and ticket.numel() == 1
+    _check(L.head_sample(R, W.shape[0], HEAD_FEATURES, _ptr(feat), _ptr(W.detach().contiguous()), _ptr(b.detach().contiguous()), int(seed),
+                         _ptr(counter), _ptr(ticket), 1 if greedy else 0, _ptr(action), _ptr(logp), _stream()), "head_sample")
+    return action, logp
 
 
 WGRAD_MIN_ROWS = 4096  # below this the BLAS library's single-workgroup-tile GEMMs are as fast

@@ -132,6 +132,18 @@ int spectral_norm_weight(int32_t A, int32_t H, const float *W, float *u, float *
                          void *stream);
 
 /*
+ * Output heads of one rollout tick (choose_action / get_value, DHGN/mappo_parallel.py:422-448), H = 128 features, A <= 16 outputs:
+ *   head_linear: y [R][A] = feat [R][H] W^T + b  (the value head: A = 1, y = the rollout's value storage).
+ *   head_sample: softmax(feat W^T + b) -> Categorical sample (Philox stream (seed, *counter + row), as categorical_sample_counter)
+ *                and its log-probability, or the argmax when greedy != 0: action [R] int32, logp [R]; *counter advances by R.
+ *                ticket: one zero-initialised uint32 in device memory owned by the caller (the kernel leaves it zero).
+ * One launch each instead of GEMM + bias (+ softmax + sample + counter update); no autograd (rollout only).
+ */
+int head_linear(int32_t R, int32_t A, int32_t H, const float *feat, const float *W, const float *b, float *y, void *stream);
+int head_sample(int32_t R, int32_t A, int32_t H, const float *feat, const float *W, const float *b, uint64_t seed, uint64_t *counter,
+                uint32_t *ticket, int32_t greedy, int32_t *action, float *logp, void *stream);
+
+/*
  * torch.nn.GRU cell between the two MFMA GEMMs (reference DHGN/mappo_parallel.py:397,424,434; gate order r, z, n):
  *   r = s(gi_r + gh_r + b_hr) ; z = s(gi_z + gh_z + b_hz) ; hn = gh_n + b_hn ; n = tanh(gi_n + r hn) ; h' = (1-z) n + z h
  * gi = x W_ih^T + b_ih [B][3H], gh = h W_hh^T [B][3H] (bias b_hh [3H] added here), h_prev / h_out [B][H];

@@ -584,3 +584,38 @@ def test_gru_reads_encoder_row_order_in_place(T, n, P):
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * a.abs().max().item())
+
+
+@pytest.mark.parametrize("R,A", [(32768, 9), (5, 9), (1001, 1), (4096, 16)])
+def test_rollout_heads_match_the_separate_kernels(R, A):
+    """head_linear == F.linear, and head_sample (action head + softmax + sample + log-prob + counter update in one launch)
+    against softmax -> categorical_sample on the same Philox stream: identical actions except where a uniform draw falls within
+    rounding of a bin edge, log-probabilities to 1e-5, the counter advanced by R, greedy = argmax."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(R + A)
+    feat = torch.randn(R, 128, device="cuda")
+    W = torch.randn(A, 128, device="cuda") * 0.2
+    b = torch.randn(A, device="cuda") * 0.1
+    with torch.no_grad():
+        y = ops.head_linear(feat, W, b)
+        assert torch.allclose(y, torch.nn.functional.linear(feat, W, b), rtol=1e-5, atol=1e-5)
+        out_v = torch.zeros(R, A, device="cuda")
+        assert ops.head_linear(feat, W, b, out=out_v).data_ptr() == out_v.data_ptr() and torch.equal(out_v, y)
+        if A == 1:
+            return
+        c0 = 12345 + (3 << 40)
+        counter = torch.full((1,), c0, dtype=torch.int64, device="cuda")
+        ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+        a_n, logp = torch.empty(R, dtype=torch.int32, device="cuda"), torch.empty(R, device="cuda")
+        ops.head_sample(feat, W, b, 77, counter, ticket, (a_n, logp))
+        assert int(counter.item()) == c0 + R and int(ticket.item()) == 0
+        prob = torch.softmax(torch.nn.functional.linear(feat, W, b), dim=-1)
+        counter2 = torch.full((1,), c0, dtype=torch.int64, device="cuda")
+        a_ref, logp_ref = ops.categorical_sample(prob, 77, 0, counter=counter2)
+        same = (a_n == a_ref)
+        assert same.float().mean().item() >= 0.999
+        assert torch.allclose(logp[same], logp_ref[same], rtol=1e-5, atol=1e-5)
+        assert torch.allclose(logp, torch.log(prob.gather(1, a_n.long()[:, None]).squeeze(1)), rtol=1e-4, atol=1e-5)
+        assert R < 1000 or a_n.unique().numel() == A
+        ops.head_sample(feat, W, b, 77, counter, ticket, (a_n, logp), greedy=True)
+        assert torch.equal(a_n.long(), prob.argmax(-1)) or (a_n.long() != prob.argmax(-1)).float().mean().item() < 1e-3
