@@ -5,7 +5,7 @@ in the loop (fused HIP env tick + batched actor/critic forward), GAE, PPO-clip/v
 samples, gradient all-reduce (RCCL) and the Adam step.  value = env-steps of all ranks / wall time.
 Synthetic data: seeded random maps, random-init weights (no datasets or checkpoints exist for this workload).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3] [--num-envs E] [--no-cpu-baseline] [--no-secondary]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4] [--num-envs E] [--no-cpu-baseline] [--no-secondary]
 
 `--gpus N` with N > 1 starts its own N rank processes (a `torch.distributed.run` child, one rank per GPU over RCCL) before
 anything in this process touches the GPU; under an outer `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
@@ -365,7 +365,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
     ap.add_argument("--num-envs", type=int, default=None, help="environments per GPU (default: the config's)")
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")

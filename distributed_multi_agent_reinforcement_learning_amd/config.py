@@ -70,6 +70,12 @@ def baseline_config(name="cfg2", **overrides):
                  "map.num_obstacle_block": 5, "algo.depth": 0, "runtime.num_envs": 4096},
         "cfg3": {"env.num_defender": 8, "map.map_size": [40, 40], "map.center": [20, 20], "map.variance": 10,
                  "map.num_obstacle_block": 5, "algo.depth": 3, "runtime.num_envs": 4096},
+        # BASELINE config 4 is a scaling configuration (16 agents, 64x64, DHGN, 8192 environments over 8 GPUs = 1024 per rank).  The
+        # environment it names has no trainer in the reference, so the shapes run on the pursuit-evasion game: 16
+        # defenders on a 64x64 map, DHGN depth 3.  Not pinned to reference vectors beyond the shared kernels (P > 8 takes the
+        # sequential step scoring of the tick; the P = 15 shipped geometry is what the parity tests cover).
+        "cfg4": {"env.num_defender": 16, "map.map_size": [64, 64], "map.center": [32, 32], "map.variance": 12,
+                 "map.num_obstacle_block": 5, "algo.depth": 3, "runtime.num_envs": 1024},
     }[name]
     ov = dict(base)
     ov["algo.use_reward_norm"] = True  # the shipped `false` crashes the reference's run_episode

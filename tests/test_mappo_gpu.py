@@ -165,14 +165,14 @@ def test_graph_replay_rollout_equals_eager_rollout():
     assert bufs[0]["a_n"].unique().numel() > 3
 
 
-@pytest.mark.parametrize("depth,P,W,H", [(0, 8, 40, 40), (1, 15, 60, 55)])
+@pytest.mark.parametrize("depth,P,W,H", [(0, 8, 40, 40), (1, 15, 60, 55), (3, 16, 64, 64)])
 def test_rollout_and_update_run_on_other_shapes(depth, P, W, H):
     """depth-0 ablation ("GRU" of BASELINE config 2; the reference's own rollout crashes at depth 0) and the
     reference's shipped 15-defender 60x55 geometry: rollout + update + optimiser step are finite and move the weights."""
     from distributed_multi_agent_reinforcement_learning_amd.mappo import MAPPO
     from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
     from tests.helpers import product_cfg
-    cfg = product_cfg(P, W, H, T=12, depth=depth, **({"map.center": [30, 25]} if W == 60 else {}))
+    cfg = product_cfg(P, W, H, T=12, depth=depth, **({"map.center": [30, 25]} if W == 60 else {}))   # (3, 16, 64, 64): BASELINE config 4's shapes
     torch.manual_seed(1)
     agent = MAPPO(cfg, 10, 4, "Learner")
     env = Pursuit_Env(cfg, num_envs=10)
