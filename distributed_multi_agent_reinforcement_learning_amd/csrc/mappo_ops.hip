@@ -103,24 +103,90 @@ __device__ __forceinline__ float msgw_row_norm(const MsgRow &m, const MsgMask &k
     return s;
 }
 
-template <int PT>
-__device__ __forceinline__ void msgw_center(const MsgDims &d, const MsgRow &m, const float (&w)[8], float bias, float (&c)[PT]) {
+// EV output features per lane (f = lane + e * blockDim): with E = 128 and EV = 2 ONE wave owns a row, so the wave-uniform part of
+// the work (read-backs, masks, bit walks, address arithmetic -- most of the instructions of a row) is issued once instead of twice
+template <int EV>
+struct FV {
+    float v[EV];
+    __device__ __forceinline__ FV() {}
+    __device__ __forceinline__ FV(float s) {
+#pragma unroll
+        for (int e = 0; e < EV; e++) v[e] = s;
+    }
+};
+#define FV_BIN(NAME, EXPR)                                                                                \
+    template <int EV> __device__ __forceinline__ FV<EV> NAME(const FV<EV> &a, const FV<EV> &b) {         \
+        FV<EV> r;                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < EV; e++) { const float x = a.v[e], y = b.v[e]; r.v[e] = EXPR; } \
+        return r;                                                                                         \
+    }                                                                                                     \
+    template <int EV> __device__ __forceinline__ FV<EV> NAME(const FV<EV> &a, float y) {                  \
+        FV<EV> r;                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < EV; e++) { const float x = a.v[e]; r.v[e] = EXPR; }          \
+        return r;                                                                                         \
+    }
+FV_BIN(operator+, x + y)
+FV_BIN(operator-, x - y)
+FV_BIN(operator*, x *y)
+FV_BIN(fv_pos, (x > 0.f) ? y : 0.f)  // y where x > 0
+#undef FV_BIN
+template <int EV> __device__ __forceinline__ FV<EV> fv_fma(const FV<EV> &a, float b, const FV<EV> &c) {
+    FV<EV> r;
+#pragma unroll
+    for (int e = 0; e < EV; e++) r.v[e] = __builtin_fmaf(a.v[e], b, c.v[e]);
+    return r;
+}
+template <int EV> __device__ __forceinline__ FV<EV> fv_relu(const FV<EV> &a) {
+    FV<EV> r;
+#pragma unroll
+    for (int e = 0; e < EV; e++) r.v[e] = fmaxf(a.v[e], 0.f);
+    return r;
+}
+template <int EV> __device__ __forceinline__ FV<EV> fv_load(const float *p, int f, int stride) {
+    FV<EV> r;
+#pragma unroll
+    for (int e = 0; e < EV; e++) r.v[e] = p[f + e * stride];
+    return r;
+}
+template <int EV> __device__ __forceinline__ void fv_store(float *p, int f, int stride, const FV<EV> &a) {
+#pragma unroll
+    for (int e = 0; e < EV; e++) p[f + e * stride] = a.v[e];
+}
+// d_j = W[:, :4] q_j, fixed evaluation order
+template <int EV> __device__ __forceinline__ FV<EV> msg_dot4v(const FV<EV> (&w)[8], const float4 &qv) {
+    return fv_fma(w[3], qv.w, fv_fma(w[2], qv.z, fv_fma(w[1], qv.y, w[0] * qv.x)));
+}
+template <int EV> __device__ __forceinline__ void msgw_weights(const MsgDims &d, const float *__restrict__ W, const float *__restrict__ b, int f,
+                                                               FV<EV> (&w)[8], FV<EV> &bias, int fs) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        w[k] = FV<EV>(0.f);
+        if (k < d.din) {
+#pragma unroll
+            for (int e = 0; e < EV; e++) w[k].v[e] = W[(size_t)(f + e * fs) * d.din + k];
+        }
+    }
+    bias = fv_load<EV>(b, f, fs);
+}
+
+template <int PT, int EV>
+__device__ __forceinline__ void msgw_center(const MsgDims &d, const MsgRow &m, const FV<EV> (&w)[8], const FV<EV> &bias, FV<EV> (&c)[PT]) {
     const float e0 = rl_f(m.ve, 0), e1 = rl_f(m.ve, 1), e2 = rl_f(m.ve, 2), e3 = rl_f(m.ve, 3);
 #pragma unroll
     for (int i = 0; i < PT; i++) {
-        c[i] = 0.f;
+        c[i] = FV<EV>(0.f);
         if (i < d.P) {
             const float p0 = rl_f(m.vp, 4 * i), p1 = rl_f(m.vp, 4 * i + 1), p2 = rl_f(m.vp, 4 * i + 2), p3 = rl_f(m.vp, 4 * i + 3);
-            c[i] = bias + w[0] * p0 + w[1] * p1 + w[2] * p2 + w[3] * p3;
-            if (d.din == 8) c[i] += w[4] * (p0 - e0) + w[5] * (p1 - e1) + w[6] * (p2 - e2) + w[7] * (p3 - e3);
+            c[i] = fv_fma(w[3], p3, fv_fma(w[2], p2, fv_fma(w[1], p1, fv_fma(w[0], p0, bias))));
+            if (d.din == 8) c[i] = fv_fma(w[7], p3 - e3, fv_fma(w[6], p2 - e2, fv_fma(w[5], p1 - e1, fv_fma(w[4], p0 - e0, c[i]))));
         }
     }
 }
 
 // the actor's aggregate of one row: acc[i] = sum_j adj_ij relu(c_i - d_j), inv[i] = 1 / max(sum_j |adj_ij|, 1e-12)
-template <int PT, bool QS, bool AS>
+template <int PT, bool QS, bool AS, int EV>
 __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const MsgRow &m, const float4 *__restrict__ q4,
-                                               const void *__restrict__ adj, const float (&w)[8], const float (&c)[PT], float (&acc)[PT],
+                                               const void *__restrict__ adj, const FV<EV> (&w)[8], const FV<EV> (&c)[PT], FV<EV> (&acc)[PT],
                                                float (&inv)[PT]) {
     const int P = d.P, K = d.K;
     if (d.adj_mode == MO_ADJ_BITS) {
@@ -128,7 +194,7 @@ __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const Ms
         const int nw = (K + 31) >> 5, RWK = MO_ADJ_ROW_WORDS(K);
 #pragma unroll
         for (int i = 0; i < PT; i++) {
-            acc[i] = 0.f;
+            acc[i] = FV<EV>(0.f);
             inv[i] = 0.f;
             if (i < P) {
                 int cnt = 0;
@@ -139,7 +205,7 @@ __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const Ms
                     while (bits) {
                         const int j = (wd << 5) + __builtin_ctz(bits);
                         bits &= bits - 1u;
-                        acc[i] += fmaxf(c[i] - msg_dot4(w, msgw_q<QS>(m, q4, j)), 0.f);
+                        acc[i] = acc[i] + fv_relu(c[i] - msg_dot4v(w, msgw_q<QS>(m, q4, j)));
                     }
                 }
                 inv[i] = 1.f / fmaxf((float)cnt, 1e-12f);
@@ -149,26 +215,26 @@ __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const Ms
         const MsgMask k = msgw_mask(m, P, K);
 #pragma unroll
         for (int i = 0; i < PT; i++) {
-            acc[i] = 0.f;
+            acc[i] = FV<EV>(0.f);
             inv[i] = 0.f;
             if (i < P) inv[i] = 1.f / fmaxf(msgw_row_norm(m, k, i, K), 1e-12f);
         }
         for (int j = 0; j < K; j++) {
             const uint64_t cm = (k.nz >> j) & k.col;  // bit i K: agent i sees neighbour j
             if (cm == 0ull) continue;
-            const float dj = msg_dot4(w, msgw_q<QS>(m, q4, j));
+            const FV<EV> dj = msg_dot4v(w, msgw_q<QS>(m, q4, j));
 #pragma unroll
             for (int i = 0; i < PT; i++)
                 if (i < P && ((cm >> (i * K)) & 1ull)) {
                     const float aij = k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, i * K + j));
-                    acc[i] = __builtin_fmaf(aij, fmaxf(c[i] - dj, 0.f), acc[i]);
+                    acc[i] = fv_fma(fv_relu(c[i] - dj), aij, acc[i]);
                 }
         }
     } else {  // MO_ADJ_TENSOR read through uniform addresses
         const float *__restrict__ ar = (const float *)adj + (size_t)r * d.adj_rs;
 #pragma unroll
         for (int i = 0; i < PT; i++) {
-            acc[i] = 0.f;
+            acc[i] = FV<EV>(0.f);
             inv[i] = 0.f;
             if (i < P) {
                 float s = 0.f;
@@ -180,56 +246,54 @@ __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const Ms
             bool any = false;
             for (int i = 0; i < P; i++) any |= ar[i * K + j] != 0.f;
             if (!any) continue;
-            const float dj = msg_dot4(w, msgw_q<QS>(m, q4, j));
+            const FV<EV> dj = msg_dot4v(w, msgw_q<QS>(m, q4, j));
 #pragma unroll
             for (int i = 0; i < PT; i++)
                 if (i < P) {
                     const float aij = ar[i * K + j];
-                    if (aij != 0.f) acc[i] = __builtin_fmaf(aij, fmaxf(c[i] - dj, 0.f), acc[i]);
+                    if (aij != 0.f) acc[i] = fv_fma(fv_relu(c[i] - dj), aij, acc[i]);
                 }
         }
     }
 }
 
 // the critic's aggregate: ones over the first kv neighbours (coordinates fetched four columns at a time)
-template <int PT, bool QS>
-__device__ __forceinline__ void msgw_ones_row(int kv, const MsgRow &m, const float4 *__restrict__ q4, const float (&w)[8], const float (&c)[PT],
-                                              float (&acc)[PT]) {
+template <int PT, bool QS, int EV>
+__device__ __forceinline__ void msgw_ones_row(int kv, const MsgRow &m, const float4 *__restrict__ q4, const FV<EV> (&w)[8], const FV<EV> (&c)[PT],
+                                              FV<EV> (&acc)[PT]) {
 #pragma unroll
-    for (int i = 0; i < PT; i++) acc[i] = 0.f;
+    for (int i = 0; i < PT; i++) acc[i] = FV<EV>(0.f);
     int j = 0;
     if (!QS) {
         for (; j + 4 <= kv; j += 4) {
             const float4 qa = q4[j], qb = q4[j + 1], qc = q4[j + 2], qd = q4[j + 3];
-            const float da = msg_dot4(w, qa), db = msg_dot4(w, qb), dc = msg_dot4(w, qc), dd = msg_dot4(w, qd);
+            const FV<EV> da = msg_dot4v(w, qa), db = msg_dot4v(w, qb), dc = msg_dot4v(w, qc), dd = msg_dot4v(w, qd);
 #pragma unroll
             for (int i = 0; i < PT; i++) {
-                acc[i] += fmaxf(c[i] - da, 0.f);
-                acc[i] += fmaxf(c[i] - db, 0.f);
-                acc[i] += fmaxf(c[i] - dc, 0.f);
-                acc[i] += fmaxf(c[i] - dd, 0.f);
+                acc[i] = acc[i] + fv_relu(c[i] - da);
+                acc[i] = acc[i] + fv_relu(c[i] - db);
+                acc[i] = acc[i] + fv_relu(c[i] - dc);
+                acc[i] = acc[i] + fv_relu(c[i] - dd);
             }
         }
     }
     for (; j < kv; j++) {
-        const float dj = msg_dot4(w, msgw_q<QS>(m, q4, j));
+        const FV<EV> dj = msg_dot4v(w, msgw_q<QS>(m, q4, j));
 #pragma unroll
-        for (int i = 0; i < PT; i++) acc[i] += fmaxf(c[i] - dj, 0.f);
+        for (int i = 0; i < PT; i++) acc[i] = acc[i] + fv_relu(c[i] - dj);
     }
 }
 
 // one relation for this workgroup's rows.  out_c == nullptr: one network (d.adj_mode decides);  else actor (out) and critic
 // (out_c; c_valid: over the first kvalid[row] neighbours) from the same messages.
-template <int PT, bool QS, bool AS>
+template <int PT, bool QS, bool AS, int EV>
 __device__ __forceinline__ void msgw_fwd_rows(const MsgDims &d, const float *__restrict__ p, const float *__restrict__ q,
                                               const float *__restrict__ e, const void *__restrict__ adj, const int32_t *__restrict__ kvalid,
                                               const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ out,
                                               float *__restrict__ out_c, bool c_valid) {
-    const int P = d.P, f = threadIdx.x;
-    float w[8];
-    for (int k = 0; k < 8; k++) w[k] = 0.f;
-    for (int k = 0; k < d.din; k++) w[k] = W[(size_t)f * d.din + k];
-    const float bias = b[f];
+    const int P = d.P, f = threadIdx.x, fs = blockDim.x;
+    FV<EV> w[8], bias;
+    msgw_weights<EV>(d, W, b, f, w, bias, fs);
     const int r0 = blockIdx.x * d.rpb, r1 = min(d.R, r0 + d.rpb);
     if (r0 >= r1) return;
     const bool use_kv = out_c != nullptr ? c_valid : d.adj_mode == MO_ADJ_VALID;
@@ -237,86 +301,86 @@ __device__ __forceinline__ void msgw_fwd_rows(const MsgDims &d, const float *__r
     for (int r = r0; r < r1; r++) {
         const MsgRow nxt = msgw_load<QS, AS>(d, r + 1 < r1 ? r + 1 : r, p, q, e, adj, kvalid, use_kv);
         const float4 *__restrict__ q4 = (const float4 *)(q + (size_t)(r / d.q_div) * d.q_rs);
-        float c[PT], acc[PT], inv[PT];
-        msgw_center<PT>(d, m, w, bias, c);
+        FV<EV> c[PT], acc[PT];
+        float inv[PT];
+        msgw_center<PT, EV>(d, m, w, bias, c);
         if (out_c != nullptr) {
-            float acv[PT];
-            msgw_ones_row<PT, QS>(m.kv, m, q4, w, c, acv);
+            FV<EV> acv[PT];
+            msgw_ones_row<PT, QS, EV>(m.kv, m, q4, w, c, acv);
             const float inv_c = 1.f / fmaxf((float)m.kv, 1e-12f);
 #pragma unroll
             for (int i = 0; i < PT; i++)
-                if (i < P) out_c[((size_t)r * P + i) * d.o_is + f] = acv[i] * inv_c;
-            msgw_actor_row<PT, QS, AS>(d, r, m, q4, adj, w, c, acc, inv);
+                if (i < P) fv_store<EV>(out_c + ((size_t)r * P + i) * d.o_is, f, fs, acv[i] * inv_c);
+            msgw_actor_row<PT, QS, AS, EV>(d, r, m, q4, adj, w, c, acc, inv);
         } else if (d.adj_mode == MO_ADJ_TENSOR || d.adj_mode == MO_ADJ_BITS) {
-            msgw_actor_row<PT, QS, AS>(d, r, m, q4, adj, w, c, acc, inv);
+            msgw_actor_row<PT, QS, AS, EV>(d, r, m, q4, adj, w, c, acc, inv);
         } else {
-            msgw_ones_row<PT, QS>(m.kv, m, q4, w, c, acc);
+            msgw_ones_row<PT, QS, EV>(m.kv, m, q4, w, c, acc);
             const float iv = 1.f / fmaxf((float)m.kv, 1e-12f);
 #pragma unroll
             for (int i = 0; i < PT; i++) inv[i] = iv;
         }
 #pragma unroll
         for (int i = 0; i < PT; i++)
-            if (i < P) out[((size_t)r * P + i) * d.o_is + f] = acc[i] * inv[i];
+            if (i < P) fv_store<EV>(out + ((size_t)r * P + i) * d.o_is, f, fs, acc[i] * inv[i]);
         m = nxt;
     }
 }
 
-template <int PT, bool QS, bool AS>
-__global__ void k_msgw_fwd(MsgDims d, const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
+template <int PT, bool QS, bool AS, int EV>
+__global__ __launch_bounds__(256) void k_msgw_fwd(MsgDims d, const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
                            const void *__restrict__ adj, const int32_t *__restrict__ kvalid, const float *__restrict__ W,
                            const float *__restrict__ b, float *__restrict__ out) {
-    msgw_fwd_rows<PT, QS, AS>(d, p, q, e, adj, kvalid, W, b, out, nullptr, false);
+    msgw_fwd_rows<PT, QS, AS, EV>(d, p, q, e, adj, kvalid, W, b, out, nullptr, false);
 }
 
 // the three relations of DHGN.encoder (defender, evader: small neighbour sets; obstacle: large) of one network (out_c == nullptr)
 // or of actor and critic together, one launch.  (kvalid2 is handed to all three calls: a literal null there crashes this
 // hipcc's inliner; relations 0 and 1 never read it.)
-template <int PT, bool S01, bool AS2>
-__global__ void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDims d2, const float *__restrict__ p, const float *__restrict__ q0,
+template <int PT, bool S01, bool AS2, int EV>
+__global__ __launch_bounds__(256) void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDims d2, const float *__restrict__ p, const float *__restrict__ q0,
                             const float *__restrict__ e0, const void *__restrict__ adj0, const float *__restrict__ W0,
                             const float *__restrict__ b0, const float *__restrict__ q1, const void *__restrict__ adj1,
                             const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ q2,
                             const void *__restrict__ adj2, const int32_t *__restrict__ kvalid2, const float *__restrict__ W2,
                             const float *__restrict__ b2, float *__restrict__ out, float *__restrict__ out_c, int c_valid) {
     const int E = d0.E;
-    msgw_fwd_rows<PT, S01, S01>(d0, p, q0, e0, adj0, kvalid2, W0, b0, out, out_c, false);
-    msgw_fwd_rows<PT, S01, S01>(d1, p, q1, e0, adj1, kvalid2, W1, b1, out + E, out_c ? out_c + E : nullptr, false);
-    msgw_fwd_rows<PT, false, AS2>(d2, p, q2, e0, adj2, kvalid2, W2, b2, out + 2 * E, out_c ? out_c + 2 * E : nullptr, c_valid != 0);
+    msgw_fwd_rows<PT, S01, S01, EV>(d0, p, q0, e0, adj0, kvalid2, W0, b0, out, out_c, false);
+    msgw_fwd_rows<PT, S01, S01, EV>(d1, p, q1, e0, adj1, kvalid2, W1, b1, out + E, out_c ? out_c + E : nullptr, false);
+    msgw_fwd_rows<PT, false, AS2, EV>(d2, p, q2, e0, adj2, kvalid2, W2, b2, out + 2 * E, out_c ? out_c + 2 * E : nullptr, c_valid != 0);
 }
 
 // backward: per-thread partial sums over the workgroup's rows -> partials [gridDim.x][din + 1][E] (reduced by
 // k_msg_agg_bwd_reduce).  dW[:, k<4] = sum_i G_i p_i[k] - sum_j H_j q_j[k] with G_i = sum_j g_ij, H_j = sum_i g_ij,
 // g_ij = [z_ij > 0] abar_ij gout_i ; dW[:, 4+k] = sum_i G_i (p_i - e)[k] ; db = sum_i G_i.  For MO_ADJ_BITS the
 // neighbour-coordinate term is summed edge by edge instead of column by column (fp32 reassociation only).
-template <int PT, bool QS, bool AS>
-__global__ void k_msgw_bwd(MsgDims d, const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
+template <int PT, bool QS, bool AS, int EV>
+__global__ __launch_bounds__(256) void k_msgw_bwd(MsgDims d, const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
                            const void *__restrict__ adj, const int32_t *__restrict__ kvalid, const float *__restrict__ W,
                            const float *__restrict__ b, const float *__restrict__ gout, float *__restrict__ partials) {
-    const int P = d.P, K = d.K, f = threadIdx.x;
-    float w[8], gw[8];
-    for (int k = 0; k < 8; k++) { w[k] = 0.f; gw[k] = 0.f; }
-    for (int k = 0; k < d.din; k++) w[k] = W[(size_t)f * d.din + k];
-    const float bias = b[f];
-    float gb = 0.f;
+    const int P = d.P, K = d.K, fs = blockDim.x, f = threadIdx.x;
+    FV<EV> w[8], gw[8], bias, gb(0.f);
+    msgw_weights<EV>(d, W, b, f, w, bias, fs);
+#pragma unroll
+    for (int k = 0; k < 8; k++) gw[k] = FV<EV>(0.f);
     const int r0 = blockIdx.x * d.rpb, r1 = min(d.R, r0 + d.rpb);
     const bool use_kv = d.adj_mode == MO_ADJ_VALID;
     MsgRow m = msgw_load<QS, AS>(d, r0 < r1 ? r0 : 0, p, q, e, adj, kvalid, use_kv);
-    float go[PT];
+    FV<EV> go[PT];
 #pragma unroll
-    for (int i = 0; i < PT; i++) go[i] = (i < P && r0 < r1) ? gout[((size_t)r0 * P + i) * d.o_is + f] : 0.f;
+    for (int i = 0; i < PT; i++) go[i] = (i < P && r0 < r1) ? fv_load<EV>(gout + ((size_t)r0 * P + i) * d.o_is, f, fs) : FV<EV>(0.f);
     for (int r = r0; r < r1; r++) {
         const int rn = r + 1 < r1 ? r + 1 : r;
         const MsgRow nxt = msgw_load<QS, AS>(d, rn, p, q, e, adj, kvalid, use_kv);
-        float gon[PT];
+        FV<EV> gon[PT];
 #pragma unroll
-        for (int i = 0; i < PT; i++) gon[i] = i < P ? gout[((size_t)rn * P + i) * d.o_is + f] : 0.f;
+        for (int i = 0; i < PT; i++) gon[i] = i < P ? fv_load<EV>(gout + ((size_t)rn * P + i) * d.o_is, f, fs) : FV<EV>(0.f);
         const float4 *__restrict__ q4 = (const float4 *)(q + (size_t)(r / d.q_div) * d.q_rs);
-        float c[PT], G[PT];
-        msgw_center<PT>(d, m, w, bias, c);
+        FV<EV> c[PT], G[PT];
+        msgw_center<PT, EV>(d, m, w, bias, c);
 #pragma unroll
-        for (int i = 0; i < PT; i++) G[i] = 0.f;
-        float hq0 = 0.f, hq1 = 0.f, hq2 = 0.f, hq3 = 0.f;
+        for (int i = 0; i < PT; i++) G[i] = FV<EV>(0.f);
+        FV<EV> hq0(0.f), hq1(0.f), hq2(0.f), hq3(0.f);
         if (d.adj_mode == MO_ADJ_BITS) {
             const uint32_t *__restrict__ bw = (const uint32_t *)adj + (size_t)r * d.adj_rs;
             const int nw = (K + 31) >> 5, RWK = MO_ADJ_ROW_WORDS(K);
@@ -329,7 +393,7 @@ __global__ void k_msgw_bwd(MsgDims d, const float *__restrict__ p, const float *
                         if (wd == (K >> 5)) bits &= (1u << (K & 31)) - 1u;
                         cnt += __popc(bits);
                     }
-                    const float gi = go[i] * (1.f / fmaxf((float)cnt, 1e-12f));
+                    const FV<EV> gi = go[i] * (1.f / fmaxf((float)cnt, 1e-12f));
                     for (int wd = 0; wd < nw; wd++) {
                         uint32_t bits = msgw_word<AS>(m, bw, i * RWK + wd);
                         if (wd == (K >> 5)) bits &= (1u << (K & 31)) - 1u;
@@ -337,81 +401,74 @@ __global__ void k_msgw_bwd(MsgDims d, const float *__restrict__ p, const float *
                             const int j = (wd << 5) + __builtin_ctz(bits);
                             bits &= bits - 1u;
                             const float4 qv = msgw_q<QS>(m, q4, j);
-                            const float g = (c[i] - msg_dot4(w, qv) > 0.f) ? gi : 0.f;
-                            G[i] += g;
-                            hq0 = __builtin_fmaf(g, qv.x, hq0); hq1 = __builtin_fmaf(g, qv.y, hq1); hq2 = __builtin_fmaf(g, qv.z, hq2); hq3 = __builtin_fmaf(g, qv.w, hq3);
+                            const FV<EV> g = fv_pos(c[i] - msg_dot4v(w, qv), gi);
+                            G[i] = G[i] + g;
+                            hq0 = fv_fma(g, qv.x, hq0); hq1 = fv_fma(g, qv.y, hq1); hq2 = fv_fma(g, qv.z, hq2); hq3 = fv_fma(g, qv.w, hq3);
                         }
                     }
                 }
-        } else if (d.adj_mode == MO_ADJ_TENSOR && AS) {
-            const MsgMask k = msgw_mask(m, P, K);
-            float gi[PT];
-#pragma unroll
-            for (int i = 0; i < PT; i++) gi[i] = i < P ? go[i] * (1.f / fmaxf(msgw_row_norm(m, k, i, K), 1e-12f)) : 0.f;
-            for (int j = 0; j < K; j++) {
-                const uint64_t cm = (k.nz >> j) & k.col;
-                if (cm == 0ull) continue;
-                const float4 qv = msgw_q<QS>(m, q4, j);
-                const float dj = msg_dot4(w, qv);
-                float hj = 0.f;
-#pragma unroll
-                for (int i = 0; i < PT; i++)
-                    if (i < P && ((cm >> (i * K)) & 1ull)) {
-                        const float aij = k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, i * K + j));
-                        const float g = (c[i] - dj > 0.f) ? gi[i] * aij : 0.f;
-                        G[i] += g;
-                        hj += g;
-                    }
-                hq0 = __builtin_fmaf(hj, qv.x, hq0); hq1 = __builtin_fmaf(hj, qv.y, hq1); hq2 = __builtin_fmaf(hj, qv.z, hq2); hq3 = __builtin_fmaf(hj, qv.w, hq3);
-            }
         } else if (d.adj_mode == MO_ADJ_TENSOR) {
-            const float *__restrict__ ar = (const float *)adj + (size_t)r * d.adj_rs;
-            float gi[PT];
+            const float *__restrict__ ar = (const float *)adj + (size_t)r * d.adj_rs;   // (!AS: through uniform addresses)
+            MsgMask k;
+            if (AS) k = msgw_mask(m, P, K);
+            FV<EV> gi[PT];
 #pragma unroll
             for (int i = 0; i < PT; i++) {
-                gi[i] = 0.f;
+                gi[i] = FV<EV>(0.f);
                 if (i < P) {
                     float s = 0.f;
-                    for (int j = 0; j < K; j++) s += fabsf(ar[i * K + j]);
+                    if (AS) s = msgw_row_norm(m, k, i, K);
+                    else for (int j = 0; j < K; j++) s += fabsf(ar[i * K + j]);
                     gi[i] = go[i] * (1.f / fmaxf(s, 1e-12f));
                 }
             }
             for (int j = 0; j < K; j++) {
-                bool any = false;
-                for (int i = 0; i < P; i++) any |= ar[i * K + j] != 0.f;
-                if (!any) continue;
+                uint64_t cm = 0ull;
+                if (AS) {
+                    cm = (k.nz >> j) & k.col;
+                    if (cm == 0ull) continue;
+                } else {
+                    bool any = false;
+                    for (int i = 0; i < P; i++) any |= ar[i * K + j] != 0.f;
+                    if (!any) continue;
+                }
                 const float4 qv = msgw_q<QS>(m, q4, j);
-                const float dj = msg_dot4(w, qv);
-                float hj = 0.f;
+                const FV<EV> dj = msg_dot4v(w, qv);
+                FV<EV> hj(0.f);
 #pragma unroll
                 for (int i = 0; i < PT; i++)
                     if (i < P) {
-                        const float aij = ar[i * K + j];
-                        if (aij != 0.f) {
-                            const float g = (c[i] - dj > 0.f) ? gi[i] * aij : 0.f;
-                            G[i] += g;
-                            hj += g;
+                        float aij;
+                        if (AS) {
+                            if (!((cm >> (i * K)) & 1ull)) continue;
+                            aij = k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, i * K + j));
+                        } else {
+                            aij = ar[i * K + j];
+                            if (aij == 0.f) continue;
                         }
+                        const FV<EV> g = fv_pos(c[i] - dj, gi[i] * aij);
+                        G[i] = G[i] + g;
+                        hj = hj + g;
                     }
-                hq0 = __builtin_fmaf(hj, qv.x, hq0); hq1 = __builtin_fmaf(hj, qv.y, hq1); hq2 = __builtin_fmaf(hj, qv.z, hq2); hq3 = __builtin_fmaf(hj, qv.w, hq3);
+                hq0 = fv_fma(hj, qv.x, hq0); hq1 = fv_fma(hj, qv.y, hq1); hq2 = fv_fma(hj, qv.z, hq2); hq3 = fv_fma(hj, qv.w, hq3);
             }
         } else {
             const int kv = m.kv;
             const float iv = 1.f / fmaxf((float)kv, 1e-12f);
-            float gi[PT];
+            FV<EV> gi[PT];
 #pragma unroll
             for (int i = 0; i < PT; i++) gi[i] = go[i] * iv;
             for (int j = 0; j < kv; j++) {
                 const float4 qv = msgw_q<QS>(m, q4, j);
-                const float dj = msg_dot4(w, qv);
-                float hj = 0.f;
+                const FV<EV> dj = msg_dot4v(w, qv);
+                FV<EV> hj(0.f);
 #pragma unroll
                 for (int i = 0; i < PT; i++) {
-                    const float g = (c[i] - dj > 0.f) ? gi[i] : 0.f;
-                    G[i] += g;
-                    hj += g;
+                    const FV<EV> g = fv_pos(c[i] - dj, gi[i]);
+                    G[i] = G[i] + g;
+                    hj = hj + g;
                 }
-                hq0 = __builtin_fmaf(hj, qv.x, hq0); hq1 = __builtin_fmaf(hj, qv.y, hq1); hq2 = __builtin_fmaf(hj, qv.z, hq2); hq3 = __builtin_fmaf(hj, qv.w, hq3);
+                hq0 = fv_fma(hj, qv.x, hq0); hq1 = fv_fma(hj, qv.y, hq1); hq2 = fv_fma(hj, qv.z, hq2); hq3 = fv_fma(hj, qv.w, hq3);
             }
         }
         const float e0 = rl_f(m.ve, 0), e1 = rl_f(m.ve, 1), e2 = rl_f(m.ve, 2), e3 = rl_f(m.ve, 3);
@@ -419,18 +476,21 @@ __global__ void k_msgw_bwd(MsgDims d, const float *__restrict__ p, const float *
         for (int i = 0; i < PT; i++)
             if (i < P) {
                 const float p0 = rl_f(m.vp, 4 * i), p1 = rl_f(m.vp, 4 * i + 1), p2 = rl_f(m.vp, 4 * i + 2), p3 = rl_f(m.vp, 4 * i + 3);
-                gb += G[i];
-                gw[0] += G[i] * p0; gw[1] += G[i] * p1; gw[2] += G[i] * p2; gw[3] += G[i] * p3;
-                if (d.din == 8) { gw[4] += G[i] * (p0 - e0); gw[5] += G[i] * (p1 - e1); gw[6] += G[i] * (p2 - e2); gw[7] += G[i] * (p3 - e3); }
+                gb = gb + G[i];
+                gw[0] = fv_fma(G[i], p0, gw[0]); gw[1] = fv_fma(G[i], p1, gw[1]); gw[2] = fv_fma(G[i], p2, gw[2]); gw[3] = fv_fma(G[i], p3, gw[3]);
+                if (d.din == 8) {
+                    gw[4] = fv_fma(G[i], p0 - e0, gw[4]); gw[5] = fv_fma(G[i], p1 - e1, gw[5]); gw[6] = fv_fma(G[i], p2 - e2, gw[6]);
+                    gw[7] = fv_fma(G[i], p3 - e3, gw[7]);
+                }
             }
-        gw[0] -= hq0; gw[1] -= hq1; gw[2] -= hq2; gw[3] -= hq3;
+        gw[0] = gw[0] - hq0; gw[1] = gw[1] - hq1; gw[2] = gw[2] - hq2; gw[3] = gw[3] - hq3;
         m = nxt;
 #pragma unroll
         for (int i = 0; i < PT; i++) go[i] = gon[i];
     }
     float *dst = partials + (size_t)blockIdx.x * (d.din + 1) * d.E;
-    for (int k = 0; k < d.din; k++) dst[k * d.E + f] = gw[k];
-    dst[d.din * d.E + f] = gb;
+    for (int k = 0; k < d.din; k++) fv_store<EV>(dst + k * d.E, f, fs, gw[k]);
+    fv_store<EV>(dst + d.din * d.E, f, fs, gb);
 }
 
 // one workgroup per output element group: 64 lanes split the partial blocks, then a wave reduction (deterministic order)
@@ -1262,7 +1322,7 @@ int check_msg(int R, int P, int K, int E, int din, int q_div, int adj_mode, cons
     return 0;
 }
 
-constexpr int BWD_BLOCKS = 2048, FWD_BLOCKS = 4096;
+constexpr int BWD_BLOCKS = 2048, FWD_BLOCKS = 8192;
 
 bool msg_q_small(int K) { return 4 * K <= 64; }
 bool msg_adj_small(int P, int K, int adj_mode) {
@@ -1731,15 +1791,17 @@ int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int
     }
     const bool s01 = msg_q_small(rel[0].K) && msg_q_small(rel[1].K) && msg_adj_small(P, rel[0].K, rel[0].adj_mode) &&
                      msg_adj_small(P, rel[1].K, rel[1].adj_mode);
-    const bool as2 = msg_adj_small(P, rel[2].K, rel[2].adj_mode);
-#define MSGW3_LAUNCH(PT, S01, AS2)                                                                                                          \
-    hipLaunchKernelGGL((k_msgw3_fwd<PT, S01, AS2>), dim3(grid), dim3(E), 0, (hipStream_t)stream, d[0], d[1], d[2], p, rel[0].q, rel[0].e,      \
-                       rel[0].adj, rel[0].W, rel[0].b, rel[1].q, rel[1].adj, rel[1].W, rel[1].b, rel[2].q, rel[2].adj, kvalid2, rel[2].W,    \
-                       rel[2].b, out, out_c, c_valid)
+    const bool as2 = msg_adj_small(P, rel[2].K, rel[2].adj_mode), ev2 = (E % 128) == 0;
+#define MSGW3_LAUNCH1(PT, S01, AS2, EV)                                                                                                     \
+    hipLaunchKernelGGL((k_msgw3_fwd<PT, S01, AS2, EV>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d[0], d[1], d[2], p, rel[0].q,       \
+                       rel[0].e, rel[0].adj, rel[0].W, rel[0].b, rel[1].q, rel[1].adj, rel[1].W, rel[1].b, rel[2].q, rel[2].adj, kvalid2,      \
+                       rel[2].W, rel[2].b, out, out_c, c_valid)
+#define MSGW3_LAUNCH(PT, S01, AS2) do { if (ev2) MSGW3_LAUNCH1(PT, S01, AS2, 2); else MSGW3_LAUNCH1(PT, S01, AS2, 1); } while (0)
 #define MSGW3_PT(PT) { if (s01 && as2) MSGW3_LAUNCH(PT, true, true); else if (s01) MSGW3_LAUNCH(PT, true, false); else if (as2) MSGW3_LAUNCH(PT, false, true); else MSGW3_LAUNCH(PT, false, false); }
     if (P <= 8) MSGW3_PT(8) else MSGW3_PT(16)
 #undef MSGW3_PT
 #undef MSGW3_LAUNCH
+#undef MSGW3_LAUNCH1
     return (int)hipGetLastError();
 }
 
@@ -1756,12 +1818,14 @@ int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
     if ((q_rs & 3) || out_stride < E) return MO_ERR_BAD_ARG;
     int grid;
     const MsgDims d = msg_dims(R, P, K, E, din, q_div, adj_mode, p_rs, q_rs, e_rs, adj_rs, out_stride, FWD_BLOCKS, &grid);
-    const bool qs = msg_q_small(K), as = msg_adj_small(P, K, adj_mode);
-#define MSGW_FWD(PT, QS, AS) hipLaunchKernelGGL((k_msgw_fwd<PT, QS, AS>), dim3(grid), dim3(E), 0, (hipStream_t)stream, d, p, q, e, adj, kvalid, W, b, out)
+    const bool qs = msg_q_small(K), as = msg_adj_small(P, K, adj_mode), ev2 = (E % 128) == 0;
+#define MSGW_FWD1(PT, QS, AS, EV) hipLaunchKernelGGL((k_msgw_fwd<PT, QS, AS, EV>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d, p, q, e, adj, kvalid, W, b, out)
+#define MSGW_FWD(PT, QS, AS) do { if (ev2) MSGW_FWD1(PT, QS, AS, 2); else MSGW_FWD1(PT, QS, AS, 1); } while (0)
 #define MSGW_FWD_PT(PT) { if (qs && as) MSGW_FWD(PT, true, true); else if (qs) MSGW_FWD(PT, true, false); else if (as) MSGW_FWD(PT, false, true); else MSGW_FWD(PT, false, false); }
     if (P <= 8) MSGW_FWD_PT(8) else MSGW_FWD_PT(16)
 #undef MSGW_FWD_PT
 #undef MSGW_FWD
+#undef MSGW_FWD1
     return (int)hipGetLastError();
 }
 
@@ -1793,13 +1857,15 @@ int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
     if ((q_rs & 3) || gout_stride < E) return MO_ERR_BAD_ARG;
     int grid;
     const MsgDims d = msg_dims(R, P, K, E, din, q_div, adj_mode, p_rs, q_rs, e_rs, adj_rs, gout_stride, BWD_BLOCKS, &grid);
-    const bool qs = msg_q_small(K), as = msg_adj_small(P, K, adj_mode);
-#define MSGW_BWD(PT, QS, AS) \
-    hipLaunchKernelGGL((k_msgw_bwd<PT, QS, AS>), dim3(grid), dim3(E), 0, (hipStream_t)stream, d, p, q, e, adj, kvalid, W, b, gout, (float *)workspace)
+    const bool qs = msg_q_small(K), as = msg_adj_small(P, K, adj_mode), ev2 = (E % 128) == 0;
+#define MSGW_BWD1(PT, QS, AS, EV) \
+    hipLaunchKernelGGL((k_msgw_bwd<PT, QS, AS, EV>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d, p, q, e, adj, kvalid, W, b, gout, (float *)workspace)
+#define MSGW_BWD(PT, QS, AS) do { if (ev2) MSGW_BWD1(PT, QS, AS, 2); else MSGW_BWD1(PT, QS, AS, 1); } while (0)
 #define MSGW_BWD_PT(PT) { if (qs && as) MSGW_BWD(PT, true, true); else if (qs) MSGW_BWD(PT, true, false); else if (as) MSGW_BWD(PT, false, true); else MSGW_BWD(PT, false, false); }
     if (P <= 8) MSGW_BWD_PT(8) else MSGW_BWD_PT(16)
 #undef MSGW_BWD_PT
 #undef MSGW_BWD
+#undef MSGW_BWD1
     const int tot = (din + 1) * E;
     hipLaunchKernelGGL(k_msg_agg_bwd_reduce, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, grid, E, din,
                        (const float *)workspace, dW, db);
