@@ -187,7 +187,8 @@ class _Trunk(nn.Module):
         hooks = list(m._forward_pre_hooks.values())
         if not hooks:
             return m.weight
-        if len(hooks) == 1 and isinstance(hooks[0], SpectralNorm) and hooks[0].name == "weight" and hooks[0].dim == 0 and m.weight_orig.dim() == 2:
+        if (len(hooks) == 1 and isinstance(hooks[0], SpectralNorm) and hooks[0].name == "weight" and hooks[0].dim == 0 and m.weight_orig.dim() == 2
+                and m.weight_orig.shape[0] <= 16 and m.weight_orig.shape[1] <= 1024):
             return ops.spectral_norm_weight(m.weight_orig, m.weight_u, m.weight_v, hooks[0].eps,
                                             hooks[0].n_power_iterations if m.training else 0)
         return None
