@@ -52,7 +52,10 @@ def build_lib(name, force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    return [build_lib(n, force=force, verbose=verbose) for n in LIBS]
+    """the four libraries side by side (hipcc is one process per library; mappo_ops.hip alone takes ~2 min)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(LIBS)) as pool:
+        return list(pool.map(lambda n: build_lib(n, force=force, verbose=verbose), LIBS))
 
 
 if __name__ == "__main__":
