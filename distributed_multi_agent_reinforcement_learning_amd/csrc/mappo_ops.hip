@@ -343,11 +343,35 @@ __global__ __launch_bounds__(256) void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDi
                             const float *__restrict__ b0, const float *__restrict__ q1, const void *__restrict__ adj1,
                             const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ q2,
                             const void *__restrict__ adj2, const int32_t *__restrict__ kvalid2, const float *__restrict__ W2,
-                            const float *__restrict__ b2, float *__restrict__ out, float *__restrict__ out_c, int c_valid) {
+                            const float *__restrict__ b2, float *__restrict__ out, float *__restrict__ out_c, int c_valid,
+                            const float *__restrict__ Wp, int64_t wp_rs, const float *__restrict__ bp, float *__restrict__ pos_a,
+                            float *__restrict__ pos_c) {
     const int E = d0.E;
     msgw_fwd_rows<PT, S01, S01, EV>(d0, p, q0, e0, adj0, kvalid2, W0, b0, out, out_c, false);
     msgw_fwd_rows<PT, S01, S01, EV>(d1, p, q1, e0, adj1, kvalid2, W1, b1, out + E, out_c ? out_c + E : nullptr, false);
     msgw_fwd_rows<PT, false, AS2, EV>(d2, p, q2, e0, adj2, kvalid2, W2, b2, out + 2 * E, out_c ? out_c + 2 * E : nullptr, c_valid != 0);
+    if (pos_a != nullptr) {
+        // the position part of DHGN's semantic layer, bp + Wp p_i (Wp = the first four input columns, :284-303), for the same rows:
+        // the addend the embedding part of that layer accumulates into; identical for actor and critic, written to both
+        const int P = d0.P, f = threadIdx.x, fs = blockDim.x, lane = threadIdx.x & 63;
+        FV<EV> wp[4], bias = fv_load<EV>(bp, f, fs);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < EV; e++) wp[k].v[e] = Wp[(size_t)(f + e * fs) * wp_rs + k];
+        const int r0 = blockIdx.x * d0.rpb, r1 = min(d0.R, r0 + d0.rpb);
+        for (int r = r0; r < r1; r++) {
+            const float vp = lane < 4 * P ? p[(size_t)r * d0.p_rs + lane] : 0.f;
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+                if (i < P) {
+                    const FV<EV> v = fv_fma(wp[3], rl_f(vp, 4 * i + 3), fv_fma(wp[2], rl_f(vp, 4 * i + 2), fv_fma(wp[1], rl_f(vp, 4 * i + 1),
+                                            fv_fma(wp[0], rl_f(vp, 4 * i), bias))));
+                    fv_store<EV>(pos_a + ((size_t)r * P + i) * E, f, fs, v);
+                    if (pos_c != nullptr) fv_store<EV>(pos_c + ((size_t)r * P + i) * E, f, fs, v);
+                }
+        }
+    }
 }
 
 // backward: per-thread partial sums over the workgroup's rows -> partials [gridDim.x][din + 1][E] (reduced by
@@ -1778,7 +1802,8 @@ int wgrad_split(int M, int N, int *am, int *bn) {  // tile shape and number of K
 }
 
 int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int64_t p_rs, const int32_t *kvalid2, float *out, float *out_c,
-                 int c_valid, int64_t out_stride, void *stream, bool pair) {
+                 int c_valid, int64_t out_stride, void *stream, bool pair, const float *Wp = nullptr, int64_t wp_rs = 0, const float *bp = nullptr,
+                 float *pos_a = nullptr, float *pos_c = nullptr) {
     MsgDims d[3];
     int grid = 1;
     for (int r = 0; r < 3; r++) {
@@ -1795,7 +1820,7 @@ int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int
 #define MSGW3_LAUNCH1(PT, S01, AS2, EV)                                                                                                     \
     hipLaunchKernelGGL((k_msgw3_fwd<PT, S01, AS2, EV>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d[0], d[1], d[2], p, rel[0].q,       \
                        rel[0].e, rel[0].adj, rel[0].W, rel[0].b, rel[1].q, rel[1].adj, rel[1].W, rel[1].b, rel[2].q, rel[2].adj, kvalid2,      \
-                       rel[2].W, rel[2].b, out, out_c, c_valid)
+                       rel[2].W, rel[2].b, out, out_c, c_valid, Wp, wp_rs, bp, pos_a, pos_c)
 #define MSGW3_LAUNCH(PT, S01, AS2) do { if (ev2) MSGW3_LAUNCH1(PT, S01, AS2, 2); else MSGW3_LAUNCH1(PT, S01, AS2, 1); } while (0)
 #define MSGW3_PT(PT) { if (s01 && as2) MSGW3_LAUNCH(PT, true, true); else if (s01) MSGW3_LAUNCH(PT, true, false); else if (as2) MSGW3_LAUNCH(PT, false, true); else MSGW3_LAUNCH(PT, false, false); }
     if (P <= 8) MSGW3_PT(8) else MSGW3_PT(16)
@@ -1843,6 +1868,17 @@ int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t 
     for (int r = 0; r < 3; r++)
         if (rel[r].adj_mode != MO_ADJ_TENSOR && rel[r].adj_mode != MO_ADJ_BITS) return MO_ERR_BAD_ARG;  // the actor's adjacency
     return launch_msgw3(rel, R, P, E, p, p_rs, o_kvalid, out_actor, out_critic, o_kvalid != nullptr, out_stride, stream, true);
+}
+
+int dhgn_msg_agg3_pair_pos_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_rs, const int32_t *o_kvalid,
+                               float *out_actor, float *out_critic, int64_t out_stride, const float *Wp, int64_t wp_row_stride, const float *bp,
+                               float *pos_actor, float *pos_critic, void *stream) {
+    if (!rel || !p || !out_actor || !out_critic || R < 0 || !Wp || !bp || !pos_actor || wp_row_stride < 4) return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    for (int r = 0; r < 3; r++)
+        if (rel[r].adj_mode != MO_ADJ_TENSOR && rel[r].adj_mode != MO_ADJ_BITS) return MO_ERR_BAD_ARG;
+    return launch_msgw3(rel, R, P, E, p, p_rs, o_kvalid, out_actor, out_critic, o_kvalid != nullptr, out_stride, stream, true, Wp, wp_row_stride, bp,
+                        pos_actor, pos_critic);
 }
 
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD_BLOCKS * (din + 1) * E * sizeof(float); }

@@ -125,15 +125,18 @@ class DHGN(nn.Module):
         R, P = p.shape[0], p.shape[1]
         E, ind = self.embedding_dim, self.input_dim
         M = self.MSG_layers
-        m3 = ops.msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
-                               o_kvalid, q_div)                                       # (2, R, P, 3, E)
-        agg0 = self.AGG_layers["AGG_vertex_0"]
-        emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)
         Ws = self.semantic_layer.weight
         h0 = out if (out is not None and self.depth == 0) else torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
-        o2 = h0.view(2, R * P, E)
-        torch.addmm(self.semantic_layer.bias, p.reshape(R * P, ind), Ws[:, :ind].t(), out=o2[0])   # position part: the same for both
-        o2[1].copy_(o2[0])
+        fused_pos = ind == 4
+        # the message launch also leaves the semantic layer's position part (the same for both networks) in h0
+        m3 = ops.msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
+                               o_kvalid, q_div, pos=(Ws[:, :ind], self.semantic_layer.bias, h0) if fused_pos else None)   # (2, R, P, 3, E)
+        agg0 = self.AGG_layers["AGG_vertex_0"]
+        emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)
+        if not fused_pos:
+            o2 = h0.view(2, R * P, E)
+            torch.addmm(self.semantic_layer.bias, p.reshape(R * P, ind), Ws[:, :ind].t(), out=o2[0])
+            o2[1].copy_(o2[0])
         h0.view(2 * R * P, E).addmm_(emb.view(2 * R * P, 3 * E), Ws[:, ind:].t())
         if self.depth == 0:
             return h0

@@ -38,6 +38,7 @@ def load_library():
         L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.dhgn_msg_agg3_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, i64, vp]
         L.dhgn_msg_agg3_pair_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp]
+        L.dhgn_msg_agg3_pair_pos_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp]
         L.spectral_norm_weight.argtypes = [i32, i32, vp, vp, vp, f32, i32, vp, vp]
         L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
         L.dhgn_msg_agg_bwd_workspace.restype = i64
@@ -237,7 +238,7 @@ def _msg3_call(L, p, rels, out, E):
            "dhgn_msg_agg3_fwd")
 
 
-def msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, o_kvalid=None, q_div=1, out=None):
+def msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, o_kvalid=None, q_div=1, out=None, pos=None):
     """(2, R, P, 3, E): msg_agg3 of the actor (slot 0: the observed adjacency) and of the critic (slot 1: ones, for the obstacle
     relation over the first o_kvalid[row] obstacles when given) from ONE pass over the messages -- the two networks share the
     encoder weights (DHGN/mappo_parallel.py:582-616).  Rollout only (no autograd); bit-identical to two msg_agg3 calls."""
@@ -255,6 +256,15 @@ def msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, o_kvalid
                          (o, None, adj_o, None, ws[4], ws[5], mode_o, q_div)))
     if o_kvalid is not None:
         assert o_kvalid.dtype == torch.int32 and o_kvalid.is_contiguous() and o_kvalid.shape[0] * q_div == R
+    if pos is not None:
+        # pos = (Wp (E, 4) -- a column slice of the semantic layer's weight --, bp (E,), h0 (2, R, P, E)): the same launch writes the
+        # layer's position part bp + Wp p for both networks into h0
+        Wp, bp, h0 = pos
+        Wp, bp = Wp.detach(), bp.detach().contiguous()
+        assert Wp.shape == (E, 4) and Wp.stride(1) == 1 and h0.shape == (2, R, P, E) and h0.is_contiguous()
+        _check(L.dhgn_msg_agg3_pair_pos_fwd(C.cast(arr, C.c_void_p), R, P, E, _ptr(p), p.stride(0), _ptr(o_kvalid), _ptr(out[0]), _ptr(out[1]), 3 * E,
+                                            _ptr(Wp), Wp.stride(0), _ptr(bp), _ptr(h0[0]), _ptr(h0[1]), _stream()), "dhgn_msg_agg3_pair_pos_fwd")
+        return out
     _check(L.dhgn_msg_agg3_pair_fwd(C.cast(arr, C.c_void_p), R, P, E, _ptr(p), p.stride(0), _ptr(o_kvalid), _ptr(out[0]), _ptr(out[1]), 3 * E,
                                     _stream()), "dhgn_msg_agg3_pair_fwd")
     return out

@@ -68,6 +68,14 @@ int dhgn_msg_agg3_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int
 int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_row_stride,
                            const int32_t *o_kvalid, float *out_actor, float *out_critic, int64_t out_stride, void *stream);
 
+/* The same launch, which also writes the position part of DHGN's semantic layer for these rows, pos[r][i][:] = bp + Wp p[r][i]
+ * (Wp [E][4]: the first four input columns of semantic_layer.weight, wp_row_stride elements between its rows; mappo_parallel.py:
+ * 284-303) -- the addend the embedding part of that layer accumulates into; the same numbers for both networks, written to
+ * pos_actor and (if not NULL) pos_critic, dense [R][P][E]. */
+int dhgn_msg_agg3_pair_pos_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_row_stride,
+                               const int32_t *o_kvalid, float *out_actor, float *out_critic, int64_t out_stride, const float *Wp,
+                               int64_t wp_row_stride, const float *bp, float *pos_actor, float *pos_critic, void *stream);
+
 /*
  * Backward of the above w.r.t. W and b (the inputs are data, they carry no gradient): recomputes the
  * pre-activation, masks with ReLU', reduces over all (r,i,j) without atomics (per-workgroup partials in

@@ -452,6 +452,12 @@ def test_actor_critic_pair_launch_equals_two_launches(P, K, q_div, valid):
             actor = ops.msg_agg3(p, e, o, adj_p, adj_e, ao, *wb, False, None, q_div)
             critic = ops.msg_agg3(p, e, o, adj_p, adj_e, ao, *wb, True, kv if valid else None, q_div)
             assert torch.equal(pair[0], actor)
+            # the same launch can leave the semantic layer's position part bp + Wp p in a (2, R, P, E) buffer
+            Wsem = (torch.randn(E, 4 + 3 * E) * 0.1).cuda(); bsem = (torch.randn(E) * 0.1).cuda()
+            h0 = torch.full((2, R, P, E), float("nan"), device="cuda")
+            pair2 = ops.msg_agg3_pair(p, e, o, adj_p, adj_e, ao, *wb, kv if valid else None, q_div, pos=(Wsem[:, :4], bsem, h0))
+            assert torch.equal(pair2, pair) and torch.equal(h0[0], h0[1])
+            assert torch.allclose(h0[0], torch.nn.functional.linear(p, Wsem[:, :4], bsem), rtol=1e-5, atol=1e-5)
             if q_div >= ops.SORTED_ONES_MIN_QDIV and not valid:   # the single-network call took the sorted kernels (reassociated sums)
                 assert torch.allclose(pair[1], critic, rtol=2e-5, atol=2e-5)
             else:
