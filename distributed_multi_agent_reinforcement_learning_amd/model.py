@@ -163,10 +163,15 @@ def _o_adj(obs):
 
 
 class _Trunk(nn.Module):
-    """shared_net -> GRU -> Mean, common to actor and critic."""
+    """shared_net -> GRU -> Mean, common to actor and critic.  use_rnn = False is the "MLP" ablation BASELINE config 1 names
+    (the reference parses --use_rnn, MAPPO_parallel_main.py:261, and never reads it): encoder -> head, the GRU (whose
+    parameters stay in the module, so checkpoints keep their keys) is bypassed and the hidden state passes through untouched."""
+    use_rnn = True
 
     def _rollout_features(self, embedding, hidden_state, inplace_hidden=False):
         R, P, E = embedding.shape
+        if not self.use_rnn:
+            return embedding, hidden_state
         feat, hidden_state = ops.gru(embedding.reshape(1, R * P, E), hidden_state, self.GRU, inplace_hidden)
         return feat.reshape(R, P, self.rnn_hidden_dim), hidden_state
 
@@ -175,6 +180,8 @@ class _Trunk(nn.Module):
         reference permutes the embedding to (steps, batch P, E) and the features back (:426-437); here the first GRU layer
         reads the rows where they lie and the (small) head outputs are permuted instead of the features."""
         P = embedding.shape[1]
+        if not self.use_rnn:
+            return embedding.reshape(batch, steps, P, self.rnn_input_dim).permute(1, 0, 2, 3)
         h0 = torch.zeros(self.num_layers, batch * P, self.rnn_hidden_dim, dtype=embedding.dtype, device=embedding.device)
         feat, _ = ops.gru(embedding.reshape(batch * steps * P, self.rnn_input_dim), h0, self.GRU, agents=P, steps=steps)
         return feat.reshape(steps, batch, P, self.rnn_hidden_dim)
@@ -278,6 +285,10 @@ def build_actor_critic(cfg, device):
     enc = DHGN(cfg.env.state_dim, cfg.algo.embedding_dim, sn, cfg.algo, device)
     actor = SharedActor(enc, cfg.algo.embedding_dim, cfg.env.action_dim, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
     critic = SharedCritic(enc, cfg.algo.embedding_dim, 1, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
+    if not bool(cfg.algo.get("use_rnn", True)):
+        if cfg.algo.embedding_dim != cfg.algo.rnn_hidden_dim:
+            raise ValueError("algo.use_rnn=false feeds the embedding to the heads: embedding_dim must equal rnn_hidden_dim")
+        actor.use_rnn = critic.use_rnn = False
     return actor.to(device), critic.to(device)
 
 

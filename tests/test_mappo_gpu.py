@@ -279,3 +279,33 @@ def test_paired_actor_critic_tick_equals_separate_forwards(depth, quirks):
     for k in bufs[0]:
         a, b = bufs[0][k].float(), bufs[1][k].float()
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (k, (a - b).abs().max())
+
+
+def test_mlp_ablation_bypasses_the_gru():
+    """algo.use_rnn = false (the "MLP" actor/critic BASELINE config 1 names): encoder -> heads.  Rollout and update run,
+    the heads see the embeddings themselves, the GRU parameters stay in the module (checkpoint keys) and receive no gradient."""
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import MAPPO
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from tests.helpers import product_cfg
+    cfg = product_cfg(4, 20, 20, T=10, depth=1, blocks=2, variance=4, **{"algo.use_rnn": False})
+    torch.manual_seed(2)
+    agent = MAPPO(cfg, 16, 8, "Learner")
+    assert not agent.actor.use_rnn and not agent.critic.use_rnn and "GRU.weight_hh_l0" in agent.actor.state_dict()
+    env = Pursuit_Env(cfg, num_envs=16)
+    exp_r, rb, steps = agent.explore_env(env, 1)
+    assert steps == 16 * 10 and torch.isfinite(rb.buffer["v_n"]).all() and torch.isfinite(rb.buffer["a_logprob_n"]).all()
+    st = agent._rstate
+    with torch.no_grad():
+        feat, h = agent.actor._rollout_features(st.a_cur, st.ha)
+    assert feat.data_ptr() == st.a_cur.data_ptr() and h is st.ha and float(st.ha.abs().max()) == 0.0
+    before = agent.actor.Mean.weight.detach().clone()
+    with torch.enable_grad():
+        objC, objA, ag, cg = agent.train(rb, steps)
+    assert np.isfinite(objC) and np.isfinite(objA)
+    names = [n for n, _ in agent.actor.named_parameters()]
+    for n, g in zip(names, ag):
+        if n.startswith("GRU."):
+            assert g is None or not np.any(g), n
+    assert any(np.any(g) for n, g in zip(names, ag) if n.startswith("Mean."))
+    agent.ac_optimizer.step()
+    assert not torch.equal(before, agent.actor.Mean.weight)
