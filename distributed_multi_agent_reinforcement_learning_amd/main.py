@@ -28,7 +28,7 @@ def main(argv=None):
             ov[k] = ast.literal_eval(v)
         except (ValueError, SyntaxError):
             ov[k] = v
-    cfg = baseline_config(args.config, **ov) if args.config in ("cfg1", "cfg2", "cfg3") else load_config(args.config, **ov)
+    cfg = baseline_config(args.config, **ov) if args.config in ("cfg1", "cfg2", "cfg3", "cfg4") else load_config(args.config, **ov)
     train_agent_multiprocessing(cfg, max_iterations=args.iterations, num_eval_envs=args.eval_envs, eval_every=args.eval_every)
 
 
