@@ -10,6 +10,7 @@
 // the only fused multiply-adds are the explicit ones in norm3 (how numpy evaluates the norm of a 3-vector).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdint.h>
 #include <string.h>
 
@@ -25,6 +26,23 @@ constexpr int WAVE = 64, WPB = 4;
 constexpr double PI = 3.14159265358979323846;
 
 __host__ __device__ inline double norm3(double a, double b, double c) { return sqrt(fma(c, c, fma(b, b, a * a))); }
+// `norm3(..) <= r` without the square root (sqrt is correctly rounded and monotonic): the squared norm -- the same fma chain the
+// norm takes the root of -- against the largest double t with sqrt(t) <= r, computed once per launch on the host
+__device__ __forceinline__ double sq3(double a, double b, double c) { return fma(c, c, fma(b, b, a * a)); }
+double sq_threshold(double r) {
+    auto ok = [&](double t) { return sqrt(t) <= r; };
+    if (!(r >= 0.0) || !ok(0.0)) return -1.0;
+    if (std::isinf(r)) return r;
+    double t = r * r;
+    while (!ok(t)) t = nextafter(t, 0.0);
+    for (;;) {
+        const double n = nextafter(t, INFINITY);
+        if (std::isinf(n) || !ok(n)) break;
+        t = n;
+    }
+    return t;
+}
+struct E3dThr { double kill, comm, sen; };
 __device__ __forceinline__ double sgn(double v) { return (double)((v > 0) - (v < 0)); }
 __device__ __forceinline__ double clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -50,7 +68,7 @@ __device__ __forceinline__ void point_step(Agent &s, double a0, double a1, doubl
 
 template <int PT, bool TICK>
 __global__ __launch_bounds__(WAVE * WPB) void k_e3d(const e3d_config c, const e3d_state st, const double *actions, const double *e_cmd, float *reward,
-                                                    uint8_t *active, uint8_t *done, const e3d_obs_out o) {
+                                                    uint8_t *active, uint8_t *done, const e3d_obs_out o, const E3dThr th) {
     constexpr int G = WAVE / PT;  // environments per wavefront
     const int lane = threadIdx.x & (WAVE - 1), wave = blockIdx.x * WPB + (threadIdx.x >> 6);
     const int g = lane / PT, a = lane - g * PT, base = lane - a;  // base: first lane of this lane's group
@@ -83,11 +101,11 @@ __global__ __launch_bounds__(WAVE * WPB) void k_e3d(const e3d_config c, const e3
         int cp = 0;
         for (int k = 0; k < P; k++) {  // wave-uniform trip count; partners through shuffles inside the group
             const double kx = __shfl(s.x, base + k), ky = __shfl(s.y, base + k), kz = __shfl(s.z, base + k), ka = __shfl(s.act, base + k);
-            cp += ka != 0.0 && norm3(s.x - kx, s.y - ky, s.z - kz) <= c.kill_radius;
+            cp += ka != 0.0 && sq3(s.x - kx, s.y - ky, s.z - kz) <= th.kill;
         }
         const bool me = pv && s.act != 0.0;
-        const int ce = me && e.act != 0.0 && norm3(s.x - e.x, s.y - e.y, s.z - e.z) <= c.kill_radius;
-        const bool e_hit = me && e.act != 0.0 && norm3(e.x - s.x, e.y - s.y, e.z - s.z) <= c.kill_radius;
+        const int ce = me && e.act != 0.0 && sq3(s.x - e.x, s.y - e.y, s.z - e.z) <= th.kill;
+        const bool e_hit = me && e.act != 0.0 && sq3(e.x - s.x, e.y - s.y, e.z - s.z) <= th.kill;
         const bool pdie = me && (cp + ce - 1) != 0;
         const bool edie = ((__ballot(e_hit) >> base) & ((PT == 64) ? ~0ull : ((1ull << PT) - 1ull))) != 0ull;
         if (pv) reward[(size_t)env * P + a] = me ? (float)(ce - (cp - 1)) : 0.f;
@@ -105,7 +123,7 @@ __global__ __launch_bounds__(WAVE * WPB) void k_e3d(const e3d_config c, const e3
             ge[0] = e.x; ge[1] = e.y; ge[2] = e.z; ge[3] = e.phi; ge[4] = e.gamma; ge[5] = e.v; ge[6] = e.act;
             const int t = st.time_step[env] + 1;
             st.time_step[env] = t;
-            const bool reach = norm3(e.x - tx, e.y - ty, e.z - tz) <= c.kill_radius;   // get_done (:221-241)
+            const bool reach = sq3(e.x - tx, e.y - ty, e.z - tz) <= th.kill;   // get_done (:221-241)
             done[env] = (uint8_t)(reach || pa == 0 || e.act == 0.0 || t >= c.max_step);
         }
     }
@@ -121,11 +139,11 @@ __global__ __launch_bounds__(WAVE * WPB) void k_e3d(const e3d_config c, const e3
     if (o.pp_adj) {
         for (int k = 0; k < P; k++) {  // row k, column a: the lanes of a group store consecutive floats
             const double kx = __shfl(s.x, base + k), ky = __shfl(s.y, base + k), kz = __shfl(s.z, base + k), ka = __shfl(s.act, base + k);
-            if (pv) o.pp_adj[(int64_t)env * o.pp_adj_stride + k * P + a] = (ka != 0.0 && norm3(kx - s.x, ky - s.y, kz - s.z) <= c.p_comm_range) ? 1.f : 0.f;
+            if (pv) o.pp_adj[(int64_t)env * o.pp_adj_stride + k * P + a] = (ka != 0.0 && sq3(kx - s.x, ky - s.y, kz - s.z) <= th.comm) ? 1.f : 0.f;
         }
     }
     if (o.pe_adj && pv)
-        o.pe_adj[(int64_t)env * o.pe_adj_stride + a] = (s.act != 0.0 && norm3(s.x - e.x, s.y - e.y, s.z - e.z) <= c.p_sen_range) ? 1.f : 0.f;
+        o.pe_adj[(int64_t)env * o.pe_adj_stride + a] = (s.act != 0.0 && sq3(s.x - e.x, s.y - e.y, s.z - e.z) <= th.sen) ? 1.f : 0.f;
 }
 
 // [N][P][7] host order -> [N][7][P] records
@@ -141,7 +159,8 @@ int launch(const e3d_config *c, const e3d_state *st, const double *actions, cons
            const e3d_obs_out &o, hipStream_t s) {
     const int pt = c->P <= 8 ? 8 : (c->P <= 16 ? 16 : (c->P <= 32 ? 32 : 64));
     const int envs_per_block = (WAVE / pt) * WPB, blocks = (st->N + envs_per_block - 1) / envs_per_block;
-#define E3D_GO(PT) hipLaunchKernelGGL((k_e3d<PT, TICK>), dim3(blocks), dim3(WAVE * WPB), 0, s, *c, *st, actions, e_cmd, reward, active, done, o)
+    const E3dThr th{sq_threshold(c->kill_radius), sq_threshold(c->p_comm_range), sq_threshold(c->p_sen_range)};
+#define E3D_GO(PT) hipLaunchKernelGGL((k_e3d<PT, TICK>), dim3(blocks), dim3(WAVE * WPB), 0, s, *c, *st, actions, e_cmd, reward, active, done, o, th)
     if (pt == 8) E3D_GO(8); else if (pt == 16) E3D_GO(16); else if (pt == 32) E3D_GO(32); else E3D_GO(64);
 #undef E3D_GO
     return (int)hipGetLastError();

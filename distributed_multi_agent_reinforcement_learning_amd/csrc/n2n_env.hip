@@ -6,6 +6,7 @@
 // Build with -ffp-contract=off; the only fused multiply-add is the explicit one in norm2 (numpy's 2-vector norm).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdint.h>
 #include <string.h>
 
@@ -21,6 +22,23 @@ constexpr int WAVE = 64;
 constexpr double PI = 3.14159265358979323846;
 
 __host__ __device__ inline double norm2(double a, double b) { return sqrt(fma(b, b, a * a)); }
+// `norm2(a, b) <= r` without the square root: sqrt is correctly rounded and monotonic, so it holds exactly when the squared norm
+// (the same fma the norm takes the root of) is <= the largest double t with sqrt(t) <= r, computed once per launch on the host.
+__device__ __forceinline__ double sq2(double a, double b) { return fma(b, b, a * a); }
+double sq_threshold(double r) {
+    auto ok = [&](double t) { return sqrt(t) <= r; };
+    if (!(r >= 0.0) || !ok(0.0)) return -1.0;  // a squared norm is >= 0: nothing qualifies
+    if (std::isinf(r)) return r;
+    double t = r * r;
+    while (!ok(t)) t = nextafter(t, 0.0);
+    for (;;) {
+        const double n = nextafter(t, INFINITY);
+        if (std::isinf(n) || !ok(n)) break;
+        t = n;
+    }
+    return t;
+}
+struct N2nThr { double kill, comm, sen; };
 __device__ __forceinline__ double sgn(double v) { return (double)((v > 0) - (v < 0)); }
 
 // particle_env.py:41-57 / :78-90 : signed heading change towards the commanded heading a, limited to ang_lmt
@@ -43,7 +61,7 @@ constexpr int WPB = 4;
 
 template <int PT, bool TICK>
 __global__ __launch_bounds__(WAVE * WPB) void k_n2n(const n2n_config c, const n2n_state st, const int32_t *actions, const double *e_cmd, float *reward,
-                                                    uint8_t *active, uint8_t *done, const n2n_obs_out o) {
+                                                    uint8_t *active, uint8_t *done, const n2n_obs_out o, const N2nThr th) {
     constexpr int G = WAVE / PT;
     constexpr unsigned long long GM = (PT == 64) ? ~0ull : ((1ull << PT) - 1ull);
     const int lane = threadIdx.x & (WAVE - 1), wave = blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -82,12 +100,12 @@ __global__ __launch_bounds__(WAVE * WPB) void k_n2n(const n2n_config c, const n2
         int ce = 0, cp = 0, chit = 0;
         for (int k = 0; k < E; k++) {
             const double kx = __shfl(ex, base + k), ky = __shfl(ey, base + k), ka = __shfl(eact, base + k);
-            ce += ka != 0.0 && norm2(px - kx, py - ky) <= c.kill_radius;
+            ce += ka != 0.0 && sq2(px - kx, py - ky) <= th.kill;
         }
         for (int k = 0; k < P; k++) {
             const double kx = __shfl(px, base + k), ky = __shfl(py, base + k), ka = __shfl(pact, base + k);
-            cp += ka != 0.0 && norm2(px - kx, py - ky) <= c.kill_radius;
-            chit += ka != 0.0 && norm2(ex - kx, ey - ky) <= c.kill_radius;   // the evader of this slot against pursuer k
+            cp += ka != 0.0 && sq2(px - kx, py - ky) <= th.kill;
+            chit += ka != 0.0 && sq2(ex - kx, ey - ky) <= th.kill;   // the evader of this slot against pursuer k
         }
         const bool p_on = pv && pact != 0.0, e_on = evv && eact != 0.0;
         if (pv) reward[(size_t)env * P + a] = p_on ? (float)(ce - (cp - 1)) : 0.f;
@@ -96,7 +114,7 @@ __global__ __launch_bounds__(WAVE * WPB) void k_n2n(const n2n_config c, const n2
         const bool pact_b = pv && pact != 0.0, eact_b = evv && eact != 0.0;
         double tx = 0, ty = 0;
         if (ev) { tx = st.target[2 * env]; ty = st.target[2 * env + 1]; }
-        const bool reach = evv && norm2(ex - tx, ey - ty) <= c.kill_radius;  // get_done (:283-304), all evaders
+        const bool reach = evv && sq2(ex - tx, ey - ty) <= th.kill;  // get_done (:283-304), all evaders
         const int pa = __popcll((__ballot(pact_b) >> base) & GM), ea = __popcll((__ballot(eact_b) >> base) & GM);
         const bool rc = ((__ballot(reach) >> base) & GM) != 0ull;
         if (pv) {
@@ -122,12 +140,12 @@ __global__ __launch_bounds__(WAVE * WPB) void k_n2n(const n2n_config c, const n2
     if (o.pp_adj)
         for (int k = 0; k < P; k++) {  // row k, column a: the lanes of a group store consecutive floats
             const double kx = __shfl(px, base + k), ky = __shfl(py, base + k), ka = __shfl(pact, base + k);
-            if (pv) o.pp_adj[(int64_t)env * o.pp_adj_stride + k * P + a] = (ka != 0.0 && norm2(kx - px, ky - py) <= c.p_comm_range) ? 1.f : 0.f;
+            if (pv) o.pp_adj[(int64_t)env * o.pp_adj_stride + k * P + a] = (ka != 0.0 && sq2(kx - px, ky - py) <= th.comm) ? 1.f : 0.f;
         }
     if (o.pe_adj)
         for (int k = 0; k < E; k++) {
             const double kx = __shfl(ex, base + k), ky = __shfl(ey, base + k);
-            if (pv) o.pe_adj[(int64_t)env * o.pe_adj_stride + a * E + k] = (pact != 0.0 && norm2(px - kx, py - ky) <= c.p_sen_range) ? 1.f : 0.f;
+            if (pv) o.pe_adj[(int64_t)env * o.pe_adj_stride + a * E + k] = (pact != 0.0 && sq2(px - kx, py - ky) <= th.sen) ? 1.f : 0.f;
         }
 }
 
@@ -137,7 +155,8 @@ int launch_n2n(const n2n_config *c, const n2n_state *st, const int32_t *actions,
     const int m = c->P > c->E ? c->P : c->E;
     const int pt = m <= 8 ? 8 : (m <= 16 ? 16 : (m <= 32 ? 32 : 64));
     const int envs_per_block = (WAVE / pt) * WPB, blocks = (st->N + envs_per_block - 1) / envs_per_block;
-#define N2N_GO(PT) hipLaunchKernelGGL((k_n2n<PT, TICK>), dim3(blocks), dim3(WAVE * WPB), 0, s, *c, *st, actions, e_cmd, reward, active, done, o)
+    const N2nThr th{sq_threshold(c->kill_radius), sq_threshold(c->p_comm_range), sq_threshold(c->p_sen_range)};
+#define N2N_GO(PT) hipLaunchKernelGGL((k_n2n<PT, TICK>), dim3(blocks), dim3(WAVE * WPB), 0, s, *c, *st, actions, e_cmd, reward, active, done, o, th)
     if (pt == 8) N2N_GO(8); else if (pt == 16) N2N_GO(16); else if (pt == 32) N2N_GO(32); else N2N_GO(64);
 #undef N2N_GO
     return (int)hipGetLastError();
