@@ -1113,10 +1113,11 @@ __global__ __launch_bounds__(64) void k_reset(const pe_config c, const pe_state 
         int tx, ty;
         for (int k = 0; k < consumed; k++) draw_target_l0(W, H, infs, pym, pyi, tx, ty);
     }
-    for (int i = lane; i < WH; i += WAVE) grid[i] = 0;
+    for (int i = lane; i < WH; i += WAVE) grid[i] = prm.fixed_grid ? prm.fixed_grid[i] : 0;
     wave_sync();
     // init_map -> add_blocker_type('r', (6, 7)): x, y in [-3, 3) around a normal(center, variance) point (Occupied_Grid_Map.py:46-62)
-    for (int b = 0; b < prm.num_blocks; b++) {
+    // (a map-bank slot in prm.fixed_grid replaces the blocks and their draws)
+    for (int b = 0; b < (prm.fixed_grid ? 0 : prm.num_blocks); b++) {
         double cx = 0.0, cy = 0.0;
         if (lane == 0) {
             py_randbelow(pym, pyi, 1u);  // random.randrange(len(shape)) with one shape

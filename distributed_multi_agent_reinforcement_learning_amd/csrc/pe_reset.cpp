@@ -168,6 +168,8 @@ bool reset_one(Resetter &R, int n, int consumed, const pe_host_init_out &o) {
 extern "C" {
 
 void *pe_resetter_create(const pe_config *cfg, const pe_reset_params *prm, int32_t N, const uint64_t *seeds) {
+    if (prm && prm->fixed_grid) return nullptr;  // a map-bank slot is a device pointer: pe_env_reset only
+
     if (!cfg || !prm || !seeds || N < 1 || pe_config_check(cfg) != 0) return nullptr;
     Resetter *R = new Resetter();
     R->cfg = *cfg;

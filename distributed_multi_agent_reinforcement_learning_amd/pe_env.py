@@ -49,7 +49,8 @@ class PeHostInit(C.Structure):
 
 
 class PeResetParams(C.Structure):
-    _fields_ = [("num_blocks", C.c_int32), ("min_dist", C.c_int32), ("center", C.c_double * 2), ("variance", C.c_double)]
+    _fields_ = [("num_blocks", C.c_int32), ("min_dist", C.c_int32), ("center", C.c_double * 2), ("variance", C.c_double),
+                ("fixed_grid", C.c_void_p)]
 
 
 class PeHostInitOut(C.Structure):
@@ -384,13 +385,23 @@ class DeviceResetter:
     """Pursuit_Env.reset() on the GPU (csrc/pe_env.hip k_reset): the generator streams of every environment live in device
     memory; same streams, same draws, same results as HostResetter, with no host arrays and no upload."""
 
-    def __init__(self, sim, cfg, seeds):
+    def __init__(self, sim, cfg, seeds, map_bank=0, bank_seed=0):
+        """map_bank = B > 0: B maps are generated once (the product's host map generator with seeds bank_seed .. bank_seed + B - 1);
+        every reset picks one slot for ALL environments (random.Random(bank_seed).randrange(B), like the older reference driver's
+        one `map_info` per node and iteration, MAPPO_parallel_main.py:103-124) and only draws targets / defenders / evader."""
         self.L = load_library()
         self.sim = sim
         self.c = sim.c
         self.N = len(seeds)
         assert self.N == sim.N
         self.prm = _reset_params(cfg)
+        self.bank = None
+        if map_bank:
+            import random as _pyrandom
+            gen = HostResetter(sim.c, cfg, [int(bank_seed) + k for k in range(int(map_bank))])
+            self.bank = torch.from_numpy(gen.reset()["grid"].reshape(int(map_bank), -1)).to(sim.device).contiguous()   # (B, W*H) u8
+            self.bank_rng = _pyrandom.Random(int(bank_seed))
+            self.bank_slot = -1
         s = _seed_array(seeds)
         n = self.L.pe_reset_state_bytes(C.byref(self.c), self.N)
         self.state = torch.empty(n, dtype=torch.uint8, device=sim.device)
@@ -399,7 +410,10 @@ class DeviceResetter:
         self.first = True
 
     def get_state(self):
-        return dict(blob=self.state.cpu().numpy(), first=self.first, device=True)
+        d = dict(blob=self.state.cpu().numpy(), first=self.first, device=True)
+        if self.bank is not None:
+            d["bank_rng"] = self.bank_rng.getstate()
+        return d
 
     def set_state(self, state):
         buf = np.ascontiguousarray(state["blob"], np.uint8)
@@ -407,12 +421,17 @@ class DeviceResetter:
             raise ValueError("resetter state does not match this configuration / number of environments / reset mode")
         self.state.copy_(torch.from_numpy(buf))
         self.first = bool(state["first"])
+        if self.bank is not None and "bank_rng" in state:
+            self.bank_rng.setstate(state["bank_rng"])
 
     def reset(self, reset_reward_norm=False):
         """Next episode of every environment, in place in the simulator state (reads the finished episode's tape position
         from the device)."""
         sim = self.sim
         sim._join()
+        if self.bank is not None:
+            self.bank_slot = self.bank_rng.randrange(self.bank.shape[0])
+            self.prm.fixed_grid = self.bank[self.bank_slot].data_ptr()
         with torch.cuda.device(sim.device):
             _check(self.L.pe_env_reset(C.byref(self.c), C.byref(sim.st), C.byref(self.prm), _ptr(self.state), 1 if self.first else 0,
                                        _ptr(sim.o_state), 1 if reset_reward_norm else 0, _stream()), "pe_env_reset")

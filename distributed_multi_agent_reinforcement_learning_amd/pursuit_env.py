@@ -36,8 +36,11 @@ class Pursuit_Env:
         self.seeds = list(seeds)
         # runtime.device_reset: the episode reset runs on the GPU (same streams and draws as the host resetter, no upload)
         self.device_reset = bool(rt.get("device_reset", False))
-        self.resetter = (pe_env.DeviceResetter(self.sim, cfg, self.seeds) if self.device_reset
-                         else pe_env.HostResetter(self.pe_cfg, cfg, self.seeds))
+        self.map_bank = int(rt.get("map_bank", 0))   # > 0: resets draw their map from a pre-generated bank (device reset only)
+        if self.map_bank and not self.device_reset:
+            raise ValueError("runtime.map_bank needs runtime.device_reset")
+        self.resetter = (pe_env.DeviceResetter(self.sim, cfg, self.seeds, self.map_bank, int(rt.get("map_bank_seed", 10 ** 6)) + 7919 * rank)
+                         if self.device_reset else pe_env.HostResetter(self.pe_cfg, cfg, self.seeds))
         self.boundary_map = SimpleNamespace(obstacle_agent=self.sim.o_state)  # (N, O, 4) [x, y, 0, 0], zero padded
         self._obs = None
         self._reward = torch.zeros((self.num_envs, self.num_defender), dtype=torch.float32, device=self.device)

@@ -127,6 +127,10 @@ typedef struct pe_reset_params {
     int32_t min_dist;         /* defender spacing, 4 in the reference */
     double center[2];         /* map.center   */
     double variance;          /* map.variance */
+    const uint8_t *fixed_grid; /* pe_env_reset only: DEVICE [W*H] u8 occupancy grid every environment starts from instead of drawing
+                                 obstacle blocks -- a slot of a pre-generated map bank (the older reference driver hands one `map_info`
+                                 per node and iteration to all its workers, MAPPO_parallel_main.py:103-124); the map-generation draws
+                                 are not taken, target / defender / attacker placement is unchanged.  NULL = draw the map. */
 } pe_reset_params;
 
 /* HOST arrays the resetter fills; same shapes as pe_host_init. */

@@ -56,10 +56,12 @@ def draw_target(inflated, rnd=_random):
 
 
 def reset_oracle(W, H, P, num_blocks, center, variance, comm_range=16, sen_range=8, min_dist=4, tape_len=0,
-                 rnd=_random, nprnd=np.random):
-    grid = np.zeros((W, H), np.uint8)
+                 rnd=_random, nprnd=np.random, fixed_grid=None):
+    """fixed_grid (W, H) u8: a pre-generated map (map-bank slot, the older reference driver's `map_info`,
+    MAPPO_parallel_main.py:103-121) replaces init_map -- its draws are not taken; everything after it is unchanged."""
+    grid = np.zeros((W, H), np.uint8) if fixed_grid is None else np.array(fixed_grid, np.uint8).reshape(W, H).copy()
     # init_map -> initailize_obstacle (Occupied_Grid_Map.py:56-62) -> add_blocker_type 'r' with data (6, 7)
-    for _ in range(num_blocks):
+    for _ in range(num_blocks if fixed_grid is None else 0):
         rnd.randrange(1)
         c = nprnd.normal(center, variance, 2)
         for x in range(-3, 3):

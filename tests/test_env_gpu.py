@@ -429,3 +429,45 @@ def test_step_scoring_stress_matches_oracle(P):
         n_clip += int(((after[..., 0] == 0) | (after[..., 0] == W - 1) | (after[..., 1] == 0) | (after[..., 1] == H - 1)).sum())
     assert n_rej > 50 and n_clip > 50, (n_rej, n_clip)   # the stress actually happened
     assert not env.status().any().item()
+
+
+def test_map_bank_reset_matches_oracle_placement_on_the_bank_map():
+    """runtime.map_bank: every reset takes ONE pre-generated map for all environments (the older reference driver's `map_info` per
+    node and iteration, MAPPO_parallel_main.py:103-124) and draws only targets / defenders / evader.  The device reset with the
+    bank slot == the oracle's reset restatement given the same grid and the same (fresh) generator streams, bit for bit; the slot
+    sequence is that of random.Random(bank seed); a rollout on the bank map runs without status bits."""
+    import random
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from oracle import reset_oracle
+    from tests.helpers import product_cfg
+    P, W, H, N, B = 8, 40, 40, 6, 5
+    cfg = product_cfg(P, W, H, T=30, **{"runtime.num_envs": N, "runtime.device_reset": True, "runtime.map_bank": B, "runtime.map_bank_seed": 77,
+                                      "runtime.seed": 300})
+    env = Pursuit_Env(cfg)
+    bank = env.resetter.bank.cpu().numpy().reshape(B, W, H)
+    assert len({g.tobytes() for g in bank}) == B                      # five different maps
+    slots = random.Random(77)
+    env.reset()
+    slot = slots.randrange(B)
+    assert env.resetter.bank_slot == slot
+    sim = env.sim
+    grids = sim.grid.cpu().numpy().reshape(N, W, H)
+    assert all(np.array_equal(g, bank[slot]) for g in grids)         # one map for every environment of the rank
+    defs, eva, tgt, tape = sim.defenders_aos().cpu().numpy(), sim.eva.cpu().numpy(), sim.target.cpu().numpy(), sim.tape.cpu().numpy()
+    for n in range(N):
+        random.seed(300 + n); np.random.seed(300 + n)
+        r = reset_oracle.reset_oracle(W, H, P, 5, [W // 2, H // 2], 10, tape_len=16, fixed_grid=bank[slot])
+        assert np.array_equal(defs[n], r["defenders"]) and np.array_equal(eva[n], r["evader"]), n
+        assert np.array_equal(tgt[n], r["target"]) and np.array_equal(tape[n], r["tape"]), n
+        k = int(sim.n_obs[n])
+        assert k == len(r["obs_xy"]) and np.array_equal(sim.o_state[n, :k, :2].cpu().numpy(), r["obs_xy"].astype(np.float32))
+    assert len({d.tobytes() for d in defs}) == N                      # placements differ between environments
+    # a short episode on the bank map, then the next reset moves to the next slot of the sequence
+    obs = sim.new_obs(); rew = torch.zeros(N, P, device="cuda")
+    env.observe(obs); env.attacker_step()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(25):
+        env.tick(torch.randint(0, 9, (N, P), generator=g, device="cuda", dtype=torch.int32), obs, rew)
+    env.reset()
+    assert env.resetter.bank_slot == slots.randrange(B)
+    assert all(np.array_equal(gr, bank[env.resetter.bank_slot]) for gr in sim.grid.cpu().numpy().reshape(N, W, H))
