@@ -1023,7 +1023,7 @@ int launch(const pe_config *cfg, const pe_state *st, const int32_t *actions, con
 }
 
 // the per-episode tables derived from the grid and the obstacle list: bidx, fresh meta / waypoint records, raser rows
-int launch_episode_tables(const pe_config *cfg, const pe_state *st, const int32_t *d_obs, const void *rng, hipStream_t s);
+int launch_episode_tables(const pe_config *cfg, const pe_state *st, const int32_t *d_obs, const void *rng, hipStream_t s, bool shared_map = false);
 
 // ---- Pursuit_Env.reset on the device ---------------------------------------------------------------------
 // The host resetter (pe_reset.cpp) restated for one wavefront per environment: the same two generator streams (CPython
@@ -1310,7 +1310,13 @@ __global__ void k_reset_seed(int N, const uint64_t *seeds, DevRng *rng) {
     R.snap_idx = 624; R.has_gauss = 0; R.has_tape = 0; R.status = 0; R.gauss = 0.0;
 }
 
-int launch_episode_tables(const pe_config *cfg, const pe_state *st, const int32_t *d_obs, const void *rng, hipStream_t s) {
+// map-bank resets: every environment holds the same grid, hence the same raser table -- built once, copied N - 1 times
+__global__ void k_bcast_raser(size_t quads_per_env, uint4 *raser) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < quads_per_env) raser[(size_t)(blockIdx.y + 1) * quads_per_env + i] = raser[i];
+}
+
+int launch_episode_tables(const pe_config *cfg, const pe_state *st, const int32_t *d_obs, const void *rng, hipStream_t s, bool shared_map) {
     if (!st->raser) return PE_ERR_NULL;
     hipLaunchKernelGGL(k_build_bidx, dim3(st->N), dim3(256), 0, s, *cfg, *st, d_obs, (const DevRng *)rng);
     const size_t lds = align16(sizeof(int16_t) * cfg->W * cfg->H) + sizeof(uint32_t) * WAVE * (raser_row_words(cfg->O) + 1);
@@ -1318,7 +1324,13 @@ int launch_episode_tables(const pe_config *cfg, const pe_state *st, const int32_
         hipError_t e = hipFuncSetAttribute((const void *)k_build_raser, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_build_raser, dim3(st->N), dim3(WAVE), lds, s, *cfg, *st);
+    const size_t quads = (size_t)cfg->W * cfg->H * raser_row_words(cfg->O) / 4;   // rows are multiples of 16 bytes
+    if (shared_map && st->N > 1 && st->N <= 65536) {
+        hipLaunchKernelGGL(k_build_raser, dim3(1), dim3(WAVE), lds, s, *cfg, *st);
+        hipLaunchKernelGGL(k_bcast_raser, dim3((unsigned)((quads + 255) / 256), (unsigned)(st->N - 1)), dim3(256), 0, s, quads, (uint4 *)st->raser);
+    } else {
+        hipLaunchKernelGGL(k_build_raser, dim3(st->N), dim3(WAVE), lds, s, *cfg, *st);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1385,7 +1397,7 @@ int pe_env_reset(const pe_config *cfg, const pe_state *st, const pe_reset_params
     DevRng *rng = (DevRng *)reset_state;
     uint8_t *bank = (uint8_t *)reset_state + N * sizeof(DevRng);
     hipLaunchKernelGGL(k_reset, dim3(N), dim3(WAVE), lds, s, *cfg, *st, *prm, rng, bank, (int)first, d_obs, d_def, o_state);
-    { const int rc2 = launch_episode_tables(cfg, st, d_obs, rng, s); if (rc2) return rc2; }
+    { const int rc2 = launch_episode_tables(cfg, st, d_obs, rng, s, prm->fixed_grid != nullptr); if (rc2) return rc2; }
     int tot = (int)(N * P * 4);
     hipLaunchKernelGGL(k_def_aos_to_soa, dim3((tot + 255) / 256), dim3(256), 0, s, (int)N, (int)P, (const double *)d_def, st->def);
     if (reset_rn) PE_TRY(hipMemsetAsync(st->rn, 0, N * (1 + 2 * P) * sizeof(double), s));

@@ -462,6 +462,16 @@ def test_map_bank_reset_matches_oracle_placement_on_the_bank_map():
         k = int(sim.n_obs[n])
         assert k == len(r["obs_xy"]) and np.array_equal(sim.o_state[n, :k, :2].cpu().numpy(), r["obs_xy"].astype(np.float32))
     assert len({d.tobytes() for d in defs}) == N                      # placements differ between environments
+    # the shared raser table (built once, copied to the other environments) == the tables pe_env_load builds per environment
+    cfg2 = product_cfg(P, W, H, T=30, **{"runtime.num_envs": N, "runtime.device_reset": False})
+    env2 = Pursuit_Env(cfg2)
+    O = cfg.map.num_max_obstacle
+    obs_xy = np.zeros((N, O, 2), np.int32)
+    n_obs = sim.n_obs.cpu().numpy()
+    for n in range(N):
+        obs_xy[n, :n_obs[n]] = sim.o_state[n, :n_obs[n], :2].cpu().numpy().astype(np.int32)
+    env2.reset(dict(grid=grids, obs_xy=obs_xy, n_obs=n_obs, defenders=defs, evader=eva, target=tgt, tape=tape))
+    assert torch.equal(env2.sim.raser, sim.raser) and torch.equal(env2.sim.bidx, sim.bidx)
     # a short episode on the bank map, then the next reset moves to the next slot of the sequence
     obs = sim.new_obs(); rew = torch.zeros(N, P, device="cuda")
     env.observe(obs); env.attacker_step()
