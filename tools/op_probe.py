@@ -25,3 +25,18 @@ for ns in (1, 4, 9):
     s = torch.randn((R, ns), device="cuda")
     t0 = timeit(lambda: torch.mm(s.t(), x)); t1 = timeit(lambda: x.sum(0)); t2 = timeit(lambda: ops.wgrad_skinny(s, x, colsum_x=True, colsum_s=True))
     print(f"skinny {R}x{ns} ^T {R}x128: mm {t0:.1f} us, sum(0) {t1:.1f} us; k_wgrad_skinny {t2:.1f} us ({R * 128 * 4 / t2 / 1e6:.2f} TB/s)")
+# DHGN.fcra neighbour mean: the rollout's paired call (4096 rows) and the update's calls on history slices (61 500 rows)
+P, E = 8, 128
+for R, T in ((4096, 1), (61500, 150)):
+    n = R // T
+    buf = torch.randn(n, T + 3, P, E, device="cuda")
+    z = buf[:, 1:1 + T] if T > 1 else buf[:, 1].contiguous()
+    adj = (torch.rand(R, P, P, device="cuda") < 0.5).float()
+    bias = torch.randn(E, device="cuda")
+    t_pair = timeit(lambda: ops.fcra_mean(z_actor=z, z_critic=z, adj=adj, bias=bias, relu=True))
+    t_a = timeit(lambda: ops.fcra_mean(z_actor=z, adj=adj))
+    t_c = timeit(lambda: ops.fcra_mean(z_critic=z))
+    zz = z.reshape(R, P, E).contiguous()
+    t_t = timeit(lambda: torch.matmul(torch.nn.functional.normalize(adj, p=1, dim=-1), zz))
+    print(f"nbr_mean R={R}: pair+bias+relu {t_pair:.1f} us, actor {t_a:.1f} us, critic {t_c:.1f} us; torch normalize+bmm {t_t:.1f} us "
+          f"(bytes: read {R * P * E * 4 / 1e6:.0f} MB, write {R * P * E * 4 / 1e6:.0f} MB per output)")
