@@ -106,8 +106,9 @@ class DHGN(nn.Module):
             agg = ops.linear(nb, aggk.weight, aggk.bias, relu=True)
             Wf = self.FCRA_layers[k].weight  # FCRA_k([agg, h]) as two accumulating GEMMs instead of a concatenation
             last = out is not None and k == self.depth - 1
-            h = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias), relu=True,
-                           out=out if last else None, consume_addend=not last)
+            # the h-part lands in the static storage on the last hop (rollout, no autograd), the agg-part accumulates into it
+            t = ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias, out=out if last else None)
+            h = ops.linear(agg, Wf[:, :E], t, relu=True, consume_addend=True)
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):
@@ -151,8 +152,9 @@ class DHGN(nn.Module):
             agg = ops.fcra_mean(z_actor=za, z_critic=zc, adj=adj_p, bias=aggk.bias, relu=True)
             Wf = self.FCRA_layers[k].weight
             last = out is not None and k == self.depth - 1
-            h = ops.linear(agg, Wf[:, :E], ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias), relu=True,
-                           out=out if last else None, consume_addend=not last)
+            # the h-part lands in the static storage on the last hop (rollout, no autograd), the agg-part accumulates into it
+            t = ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias, out=out if last else None)
+            h = ops.linear(agg, Wf[:, :E], t, relu=True, consume_addend=True)
         return h
 
 

@@ -634,6 +634,9 @@ def _linear_fwd(x, W, b, out=None, relu=False, consume_addend=False):
     if out is None:  # the result is allocated in its final shape: a base tensor, not a view (it may be consumed in place later)
         res = torch.empty(oshape, dtype=x.dtype, device=x.device)
         out = res.view(-1, W.shape[0])
+    elif out.dim() != 2:  # caller's storage in the result's shape
+        res = out
+        out = out.view(-1, W.shape[0])
     if b is None:
         y = torch.mm(x2, W.t(), out=out)
     else:
