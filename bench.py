@@ -6,6 +6,7 @@ samples, gradient all-reduce (RCCL) and the Adam step.  value = env-steps of all
 Synthetic data: seeded random maps, random-init weights (no datasets or checkpoints exist for this workload).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4] [--num-envs E] [--no-cpu-baseline] [--no-secondary]
+                  [--scaling weak|strong [--total-envs E]]
 
 `--gpus N` with N > 1 starts its own N rank processes (a `torch.distributed.run` child, one rank per GPU over RCCL) before
 anything in this process touches the GPU; under an outer `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
@@ -27,7 +28,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TF = 157.3    # fp32 vector == fp32 MFMA peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_tick_pmc.json")
+PMC_FILES = {"packed": [os.path.join(ROOT, "profiles", n) for n in ("r03_tick_pmc.json", "r02_tick_pmc.json")],   # newest first
+             "fp32": [os.path.join(ROOT, "profiles", "r03_tick_pmc_fp32.json")]}
 
 
 def algorithmic_bytes_per_env_step(P, W, H, O):
@@ -45,19 +47,26 @@ def tick_kernel_hash():
     return h.hexdigest()[:16]
 
 
-def load_pmc_traffic(N, us_live):
+def load_pmc_traffic(N, us_live, layout="packed"):
     """HBM bytes per launch of the regular tick from the committed rocprofv3 PMC passes (tools/pmc_summary.py; FETCH_SIZE
     doubled per MI355X_MICROARCH.md, WRITE_SIZE as read).  Counters cannot be collected inside this process, so the record
     is only used when it was captured on THIS kernel source (hash) at this size and its launch duration agrees with the
     live one; otherwise traffic is null and the reason is reported."""
-    try:
-        j = json.load(open(PMC_FILE))
-    except Exception:
-        return None, "no PMC record (profiles/r02_tick_pmc.json)"
-    if j.get("num_envs") != N:
-        return None, f"PMC record is for {j.get('num_envs')} environments"
-    if j.get("kernel_hash") != tick_kernel_hash():
-        return None, "PMC record is stale: csrc/pe_env.hip / include/pe_env.h changed since it was captured"
+    j, why = None, "no PMC record under profiles/"
+    for path in PMC_FILES[layout]:
+        try:
+            cand = json.load(open(path))
+        except Exception:
+            continue
+        if cand.get("num_envs") != N:
+            why = f"PMC record is for {cand.get('num_envs')} environments"
+        elif cand.get("kernel_hash") != tick_kernel_hash():
+            why = "PMC record is stale: csrc/pe_env.hip / include/pe_env.h changed since it was captured"
+        else:
+            j = cand
+            break
+    if j is None:
+        return None, why
     us_rec = j.get("us_per_launch")
     if us_rec and abs(us_rec - us_live) > 0.25 * us_live:
         return None, f"PMC record's launch duration ({us_rec:.1f} us) disagrees with the live run ({us_live:.1f} us)"
@@ -158,20 +167,31 @@ def measure_compute_kernels(trainer, cfg):
         wi, wh, bi, bh = w, torch.randn(384, 128, device=dev) * 0.08, b, torch.zeros(384, device=dev)
         t = timeit(lambda: L.gru_cell_fwd(Br, 128, ptr(xr), ptr(hr), ptr(wi), ptr(wh), ptr(bi), ptr(bh), ptr(ho), st), n=20)  # C ABI directly
         out["gru_cell"] = entry("k_gru_cell (one rollout GRU layer step: both projections + gates, one launch)", 2.0 * Br * 128 * 768, t, rows=Br)
+    # DHGN message + mean aggregation: the kernels never form the (rows, P, K, E) message, so flops of the reference formulation are
+    # not a hardware figure for them; they are priced by the bytes they must move (inputs + the (rows, P, relations, E) output)
     R = mb * T
-    p = torch.rand(R, P, 4, device=dev) * 40; q = torch.zeros(mb, O, 4, device=dev); q[:, :, :2] = torch.randint(0, 40, (mb, O, 2), device=dev).float()
-    W = torch.randn(E, 4, device=dev) * 0.3; bb = torch.zeros(E, device=dev)
-    fl_alg = R * P * O * (2 * 4 * E + 3 * E)
-    note = ("`achieved` prices the reference formulation W (p_i - q_j) + b -> relu -> mean (11 E flops per pair, SURVEY 8d): an "
-            "algorithmic-equivalent rate, not a hardware fraction; the kernel executes far fewer flops")
+    p = torch.rand(R, P, 4, device=dev) * 40; e = torch.rand(R, 1, 4, device=dev) * 40
+    q = torch.zeros(mb, O, 4, device=dev); q[:, :, :2] = torch.randint(0, 40, (mb, O, 2), device=dev).float()
+    adj_p = (torch.rand(R, P, P, device=dev) < 0.6).float(); adj_e = (torch.rand(R, P, 1, device=dev) < 0.3).float()
+    adj_o = ops.pack_adj_bits((torch.rand(R, P, O, device=dev) < 0.1).float())
+    Ws = [torch.randn(E, 8, device=dev) * 0.3, torch.randn(E, 4, device=dev) * 0.3, torch.randn(E, 4, device=dev) * 0.3]
+    bs = [torch.zeros(E, device=dev) for _ in range(3)]
+
+    def hbm_entry(kernel, nbytes, t, **kw):
+        return dict(bound="hbm", kernel=kernel, achieved=round(nbytes / t / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), us_per_launch=round(t * 1e6, 1), bytes_per_launch=int(nbytes), **kw)
+    in_bytes = 4 * (p.numel() + e.numel() + q.numel() + adj_p.numel() + adj_e.numel() + adj_o.numel())
     with torch.no_grad():
-        t = timeit(lambda: ops.msg_agg(p, q, None, None, W, bb, ops.ADJ_ONES, None, T))
-    out["msg_agg_fwd_dense"] = entry("dhgn_msg_agg_fwd(MO_ADJ_ONES): O(K) loop per pair (the rollout's critic relation uses this form over the real obstacles)",
-                                     fl_alg, t, bound="valu", rows=R, note=note)
+        t = timeit(lambda: ops.msg_agg3(p, e, q, adj_p, adj_e, adj_o, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2], False, None, T))
+    out["msg_agg3_fwd_actor"] = hbm_entry("k_msgw3_fwd: the actor's three relations of one mini-batch in one launch (packed LiDAR rows walked edge by edge)",
+                                          in_bytes + 4.0 * R * P * 3 * E, t, rows=R)
+    L = ops.load_library()
+    ptr = lambda t_: C.c_void_p(t_.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     oo = torch.empty(R, P, E, device=dev)
-    t = timeit(lambda: L.dhgn_msg_agg_ones_sorted_fwd(R, P, O, E, ptr(p), p.stride(0), ptr(q), q.stride(0), T, ptr(W), ptr(bb), ptr(oo), E, None, None, st))
-    out["msg_agg_fwd"] = entry("dhgn_msg_agg_ones_sorted_fwd: the update's critic obstacle relation, sort + prefix sums + binary search, O(log K) per pair",
-                               fl_alg, t, bound="valu", rows=R, note=note)
+    t = timeit(lambda: L.dhgn_msg_agg_ones_sorted_fwd(R, P, O, E, ptr(p), p.stride(0), ptr(q), q.stride(0), T, ptr(Ws[2]), ptr(bs[2]), ptr(oo), E, None, None, st))
+    out["msg_agg_ones_sorted_fwd_critic"] = hbm_entry("k_msg_ones_sorted_fwd: the update's critic obstacle relation (all-ones adjacency): per-episode sort + prefix "
+                                                      "sums + binary search, O(log K) per pair", 4.0 * (p.numel() + q.numel()) + 4.0 * R * P * E, t, rows=R)
     return out
 
 
@@ -298,6 +318,11 @@ def run_config(name, args, with_roofline):
     if args.max_steps:
         ov["env.max_steps"] = args.max_steps
     cfg = baseline_config(name, **ov)
+    if args.scaling == "strong":   # fixed total: the job's environments are divided over the ranks (BASELINE configs 4 / 5 state totals)
+        total = int(args.total_envs or cfg.runtime.num_envs)
+        if total % world:
+            raise SystemExit(f"--scaling strong: {total} environments do not divide over {world} ranks")
+        cfg.runtime.num_envs = total // world
     tr = Trainer(cfg)  # weak scaling: every rank owns runtime.num_envs environments
     N, T, P = tr.num_envs, cfg.env.max_steps, cfg.env.num_defender
     W, H = cfg.map.map_size
@@ -329,23 +354,48 @@ def run_config(name, args, with_roofline):
                workload=f"{name}: pursuit_evasion_game {P} defenders, {W}x{H} map, {N} envs/GPU, T={T}, DHGN depth {cfg.algo.depth} + "
                         f"2-layer GRU actor/critic, rollout + PPO update",
                envs_per_gpu=N, episode_steps=T, mini_batch_size=tr.mini_batch_size, backend=(dist.get_backend() if world > 1 else None))
+    # GEMM-shaped algorithmic work of one iteration (SURVEY 8d F_net without the message terms, which the kernels do not execute as
+    # flops): per network and env-step; the rollout runs each network forward once, every epoch of the update forward + backward (3x)
+    E_, H_, A_, d_ = cfg.algo.embedding_dim, cfg.algo.rnn_hidden_dim, cfg.env.action_dim, cfg.algo.depth
+    f_net = (3 * 2 * P * E_ * E_ + 2 * P * (3 * E_ + 4) * E_ + d_ * (2 * P * P * E_ + 2 * P * E_ * E_ + 2 * P * 2 * E_ * E_)
+             + (cfg.algo.num_layers * 2 * (2 * P * E_ * 3 * H_) if cfg.algo.get("use_rnn", True) else 0) + 2 * P * H_ * A_)
+    flops_iter = 2 * f_net * (1 + 3 * int(cfg.algo.epochs)) * N * T
+    res["roofline_iteration"] = {"bound": "mfma", "what": "GEMM-shaped algorithmic flops of one iteration (both networks: rollout forward + update forward and "
+                                 "backward) over the measured iteration time", "flops_per_net_env_step": f_net, "flops_per_iteration": flops_iter,
+                                 "achieved": round(flops_iter / (dt / args.steps) / 1e12, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": round(flops_iter / (dt / args.steps) / 1e12 / FP32_PEAK_TF, 4)}
     if with_roofline:
         tk = measure_env_tick(tr, args.tick_samples)
         tk_f32 = measure_env_tick(tr, args.tick_samples, packed=False)
-        bytes_per_step = algorithmic_bytes_per_env_step(P, W, H, O)
-        achieved = N * bytes_per_step / tk["regular"] / 1e9
+        bytes_f32 = algorithmic_bytes_per_env_step(P, W, H, O)                       # reference fp32 observation layout
+        bytes_packed = bytes_f32 - 4 * P * O + 4 * P * (((O + 31) // 32 + 3) // 4 * 4)   # LiDAR rows as PE_RASER_ROW_WORDS(O) words
         traffic, why = load_pmc_traffic(N, tk["regular"] * 1e6)
-        res["roofline"] = {"bound": "hbm", "kernel": "k_tick<step,observe,evader,no-replan> (csrc/pe_env.hip)", "achieved": round(achieved, 2),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "bytes_per_env_step": bytes_per_step, "us_per_launch": round(tk["regular"] * 1e6, 2), "env_steps_per_launch": N,
-                           "episode_avg_tick_us": round(tk["avg"] * 1e6, 2),
-                           "observation_layout": "the launch the rollout issues: LiDAR rows (o_adj) leave the kernel bit-packed, 32 B per defender "
-                                                 "instead of 704 B; `achieved` prices the reference's fp32 layout (SURVEY 8d grades on it)",
-                           "bytes_per_env_step_packed_layout": bytes_per_step - 4 * P * O + 4 * P * (((O + 31) // 32 + 3) // 4 * 4),
-                           "us_per_launch_fp32_o_adj": round(tk_f32["regular"] * 1e6, 2),
-                           "frac_fp32_o_adj": round(N * bytes_per_step / tk_f32["regular"] / 1e9 / HBM_PEAK_GBS, 5)}
+        traffic_f32, why_f32 = load_pmc_traffic(N, tk_f32["regular"] * 1e6, "fp32")
+        # Every figure divides the bytes of ONE layout by the launch duration of the kernel variant that writes THAT layout.
+        # `roofline` is the variant SURVEY 8(d) grades (fp32 rows, the C ABI's pe_obs_out.o_adj); the timed training loop issues the
+        # packed variant, reported next to it with its own bytes and time and with the PMC-measured HBM rate.
+        ach_f32 = N * bytes_f32 / tk_f32["regular"] / 1e9
+        ach_packed = N * bytes_packed / tk["regular"] / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": "k_tick<step,observe,evader,no-replan> writing the reference's fp32 observation layout (csrc/pe_env.hip)",
+                           "achieved": round(ach_f32, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_f32 / HBM_PEAK_GBS, 5),
+                           "traffic": traffic_f32,
+                           "hbm_actual_GBps": None if traffic_f32 is None else round(traffic_f32 / tk_f32["regular"] / 1e9, 1),
+                           "bytes_per_env_step": bytes_f32, "us_per_launch": round(tk_f32["regular"] * 1e6, 2), "env_steps_per_launch": N,
+                           "episode_avg_tick_us": round(tk_f32["avg"] * 1e6, 2)}
+        res["roofline_packed_rows"] = {"bound": "hbm", "kernel": "the same kernel with LiDAR rows bit-packed (32 B per defender instead of 704 B): the launch "
+                                       "the rollout issues", "achieved": round(ach_packed, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(ach_packed / HBM_PEAK_GBS, 5), "traffic": traffic, "bytes_per_env_step": bytes_packed,
+                                       "us_per_launch": round(tk["regular"] * 1e6, 2), "env_steps_per_launch": N,
+                                       "episode_avg_tick_us": round(tk["avg"] * 1e6, 2),
+                                       "hbm_actual_GBps": None if traffic is None else round(traffic / tk["regular"] / 1e9, 1),
+                                       "hbm_actual_frac": None if traffic is None else round(traffic / tk["regular"] / 1e9 / HBM_PEAK_GBS, 5),
+                                       "fp32_equivalent_GBps": round(N * bytes_f32 / tk["regular"] / 1e9, 1),
+                                       "fp32_equivalent_note": "reference-layout bytes over the packed launch's time: a cross-layout throughput equivalent, "
+                                                               "not a bandwidth (rounds 1-2 reported this as roofline.achieved)"}
         if why:
-            res["roofline"]["traffic_note"] = why
+            res["roofline_packed_rows"]["traffic_note"] = why
+        if why_f32:
+            res["roofline"]["traffic_note"] = why_f32
         res["roofline_replan_tick"] = {"kernel": "k_tick<..., replan> (rescan + weighted A* of every evader, every `difficulty` ticks)",
                                        "bound": "instruction issue of the slowest wave (stragglers), not bytes",
                                        "us_per_launch": round(tk["replan"] * 1e6, 1), "us_max": round(tk["replan_max"] * 1e6, 1),
@@ -371,6 +421,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 measurement that rides along with cfg2")
     ap.add_argument("--tick-samples", type=int, default=150)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank owns the config's environments; strong: --total-envs (default: the config's count) divided over the ranks")
+    ap.add_argument("--total-envs", type=int, default=None, help="--scaling strong: environments of the whole job")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -399,18 +452,21 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node), pursuit-evasion 8-agent 4096-env", "value": main_res["value"],
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64 environment / f32 policy", "data": "synthetic (seeded random maps, random-init weights)",
             "config": {"workload": main_res["workload"], "envs_per_gpu": main_res["envs_per_gpu"], "episode_steps": main_res["episode_steps"],
-                       "mini_batch_size": main_res["mini_batch_size"], "parallelism": f"dp{world}",
+                       "mini_batch_size": main_res["mini_batch_size"],
+                       "parallelism": f"dp{world} ({args.scaling} scaling: " + (f"{main_res['envs_per_gpu'] * world} environments in total, {main_res['envs_per_gpu']} per rank)"
+                                                                                 if args.scaling == "strong" else f"{main_res['envs_per_gpu']} environments on every rank)"),
                        "collective": (f"torch.distributed {main_res['backend']} all_reduce(SUM) of one flat fp32 gradient bucket per epoch"
                                       if world > 1 else None)},
             "ppo_updates_per_s": main_res["ppo_updates_per_s"], "breakdown_ms": main_res["breakdown_ms"],
-            "roofline": main_res["roofline"], "roofline_replan_tick": main_res["roofline_replan_tick"],
+            "roofline": main_res["roofline"], "roofline_packed_rows": main_res["roofline_packed_rows"],
+            "roofline_iteration": main_res["roofline_iteration"], "roofline_replan_tick": main_res["roofline_replan_tick"],
             "roofline_compute_kernels": main_res.get("roofline_compute_kernels", {}),
         }
         if second is not None:
-            out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "workload")}}
+            out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "workload", "roofline_iteration")}}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

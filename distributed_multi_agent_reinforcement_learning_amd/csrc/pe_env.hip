@@ -931,6 +931,39 @@ __global__ __launch_bounds__(WAVE) void k_astar(int W, int H, int n, const uint8
     if (lane == 0) { out_len[2 * b] = len; out_len[2 * b + 1] = nexp; }
 }
 
+// ---- Pursuit_Env.demon (pursuit_env.py:211-229): the scripted pursuer -- the discrete action whose direction is closest to the
+// bearing of the evader.  One lane per defender.  The reference evaluates action = (cos(phi), sin(phi)), phi = sign(dy) *
+// arccos(dx / (radius + 1e-3)); here cos(arccos q) = q and sin(arccos q) = sqrt((1 - q)(1 + q)) (the same restatement as the
+// evader's heading: numpy's arccos / cos / sin are not reproducible to the last bit across CPUs).  The result is an
+// arg-min over nine distances whose runner-up is >= 0.39 away except on the eight bisector bearings, so the 1-2 ulp between the
+// two forms cannot change an action off a measure-zero set; pinned by the recorded demon actions of the reference traces.
+// sign(0) = 0 gives phi = 0, i.e. action 0, also for an evader straight to the left (kept).
+struct DemonDirs { double d[9][2]; };
+__global__ void k_demon(int N, int P, const double *__restrict__ def, const double *__restrict__ eva, DemonDirs dirs, int32_t *__restrict__ actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * P) return;
+    const int n = i / P, a = i - n * P;
+    const double *rec = def + (size_t)n * 4 * P;
+    const double x = rec[a], y = rec[P + a], ex = eva[(size_t)n * 4], ey = eva[(size_t)n * 4 + 1];
+    const double radius = norm2(x - ex, y - ey);
+    double ax = 0.0, ay = 0.0;
+    if (!(radius <= 0.01)) {   // math.isclose(radius, 0.0, abs_tol=0.01) with the default rel_tol is radius <= 0.01
+        const double dy = ey - y;
+        const double sg = dy > 0.0 ? 1.0 : (dy < 0.0 ? -1.0 : 0.0);
+        const double q = (ex - x) / (radius + 1e-3);
+        if (sg == 0.0) { ax = 1.0; ay = 0.0; }
+        else { ax = q; ay = sg * __builtin_sqrt((1.0 - q) * (1.0 + q)); }
+    }
+    int best = 0;
+    double bd = norm2(dirs.d[0][0] - ax, dirs.d[0][1] - ay);
+#pragma unroll
+    for (int k = 1; k < 9; k++) {
+        const double dk = norm2(dirs.d[k][0] - ax, dirs.d[k][1] - ay);
+        if (dk < bd) { bd = dk; best = k; }   // list.index(min(..)): the first minimum
+    }
+    actions[i] = best;
+}
+
 __global__ void k_diag_norm2(int n, const double *a, const double *b, double *out, double c0, double y0, double c1, double y1) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -1446,6 +1479,16 @@ int pe_evader_step(const pe_config *cfg, const pe_state *st, int32_t may_replan,
     if (!cfg || !st) return PE_ERR_NULL;
     return may_replan ? launch<false, false, true, true>(cfg, st, nullptr, nullptr, nullptr, stream)
                       : launch<false, false, true, false>(cfg, st, nullptr, nullptr, nullptr, stream);
+}
+
+int pe_env_demon(const pe_config *cfg, const pe_state *st, const double *unit_dirs, int32_t *actions, void *stream) {
+    if (!cfg || !st || !unit_dirs || !actions || !st->def || !st->eva) return PE_ERR_NULL;
+    DemonDirs dd;
+    memcpy(dd.d, unit_dirs, sizeof dd.d);
+    const int n = st->N * cfg->P;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_demon, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, st->N, cfg->P, st->def, st->eva, dd, actions);
+    return (int)hipGetLastError();
 }
 
 int pe_env_step(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *out, void *stream) {

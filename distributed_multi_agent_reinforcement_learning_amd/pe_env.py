@@ -58,7 +58,7 @@ class PeHostInitOut(C.Structure):
 
 
 EXPORTS = ("pe_config_check", "pe_tick_lds_bytes", "pe_env_load", "pe_env_observe", "pe_evader_step", "pe_env_step",
-           "pe_env_tick", "pe_env_step_observe", "pe_astar_batch", "pe_error_string")
+           "pe_env_demon", "pe_env_tick", "pe_env_step_observe", "pe_astar_batch", "pe_error_string")
 
 _lib = None
 
@@ -84,6 +84,7 @@ def load_library():
         L.pe_env_observe.argtypes = [vp, vp, vp, vp]
         L.pe_evader_step.argtypes = [vp, vp, C.c_int32, vp]
         L.pe_env_step.argtypes = [vp, vp, vp, vp, vp]
+        L.pe_env_demon.argtypes = [vp, vp, vp, vp, vp]
         L.pe_env_tick.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
         L.pe_env_step_observe.argtypes = [vp, vp, vp, vp, vp, vp]
         L.pe_astar_batch.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]
@@ -335,6 +336,16 @@ class BatchedEnv:
             self._pending = True
             return
         _check(self.L.pe_env_tick(C.byref(self.c), C.byref(self.st), _ptr(a), C.byref(s), C.byref(o), replan, _stream()), "pe_env_tick")
+
+    def demon(self, out=None):
+        """Pursuit_Env.demon (pursuit_env.py:211-229) for every environment -> (N, P) int32 actions (csrc/pe_env.hip k_demon)."""
+        self._join()
+        if out is None:
+            out = torch.empty((self.N, self.c.P), dtype=torch.int32, device=self.device)
+        assert out.dtype == torch.int32 and out.is_contiguous() and out.shape == (self.N, self.c.P)
+        dirs = (C.c_double * 18)(*[v for cs in tables.action_table(1.0) for v in cs])
+        _check(self.L.pe_env_demon(C.byref(self.c), C.byref(self.st), dirs, _ptr(out), _stream()), "pe_env_demon")
+        return out
 
     def _actions(self, actions):
         if actions.dtype != torch.int32:

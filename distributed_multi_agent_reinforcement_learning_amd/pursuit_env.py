@@ -6,7 +6,6 @@ environment dimension N (one reference `Worker` each).  The simulation runs in c
 include/pe_env.h; the episode reset runs in csrc/pe_reset.cpp with per-environment replicas of the reference's RNG
 streams (environment n of rank r is seeded `seed + max(1000, num_envs) * r + n`).
 """
-import math
 from types import SimpleNamespace
 
 import numpy as np
@@ -144,20 +143,9 @@ class Pursuit_Env:
         return self._raw, self.time_step >= self.max_steps, None
 
     def demon(self):
-        """pursuit_env.py:211-229: scripted pursuit, the discrete action closest to the bearing of the evader."""
-        d = self.sim.defenders_aos()
-        e = self.sim.eva
-        dx, dy = e[:, None, 0] - d[:, :, 0], e[:, None, 1] - d[:, :, 1]
-        radius = torch.sqrt(dx * dx + dy * dy)
-        phi = torch.sign(dy) * torch.arccos(dx / (radius + 1e-3))
-        ax, ay = torch.cos(phi), torch.sin(phi)
-        still = radius <= 0.01
-        ax = torch.where(still, torch.zeros_like(ax), ax)
-        ay = torch.where(still, torch.zeros_like(ay), ay)
-        th = torch.tensor([i * math.pi / 4 for i in range(8)], dtype=torch.float64, device=self.device)
-        tab = torch.stack((torch.cat((torch.cos(th), th.new_zeros(1))), torch.cat((torch.sin(th), th.new_zeros(1)))), -1)
-        dist = torch.sqrt((tab[None, None, :, 0] - ax[..., None]) ** 2 + (tab[None, None, :, 1] - ay[..., None]) ** 2)
-        return dist.argmin(-1)
+        """pursuit_env.py:211-229: scripted pursuit, the discrete action closest to the bearing of the evader -> (N, P) int32
+        (one launch, csrc/pe_env.hip k_demon; pinned by the demon actions recorded in the reference traces)."""
+        return self.sim.demon()
 
     def get_done(self):
         return self.time_step >= self.max_steps

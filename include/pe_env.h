@@ -184,6 +184,11 @@ int pe_evader_step(const pe_config *cfg, const pe_state *st, int32_t may_replan,
 /* Pursuit_Env.step (pursuit_env.py:104-149) + reward normalisation (DHGN/normalization.py:29-35). */
 int pe_env_step(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *out, void *stream);
 
+/* Pursuit_Env.demon (pursuit_env.py:211-229): the scripted pursuit policy, one discrete action per defender -- the action whose
+ * direction is closest to the bearing of the evader ((0, 0) within 0.01 of it).  unit_dirs: HOST [9][2] doubles, the reference's
+ * `actions_mat` (cos, sin of k pi / 4, then (0, 0)); actions: DEVICE [N][P] int32. */
+int pe_env_demon(const pe_config *cfg, const pe_state *st, const double *unit_dirs, int32_t *actions, void *stream);
+
 /* Fused rollout tick: step(actions) -> observe -> attacker_step in ONE launch (the order of
  * DHGN/mappo_parallel.py:793 followed by :759-765 of the next loop iteration). */
 int pe_env_tick(const pe_config *cfg, const pe_state *st, const int32_t *actions, const pe_step_out *sout,

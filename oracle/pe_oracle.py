@@ -163,6 +163,28 @@ class OracleEnv:
         return f[:self.n_obs]
 
 
+def demon(defenders, evader):
+    """Pursuit_Env.demon restated line by line (reference environment/pursuit_evasion_game/pursuit_env.py:211-229), numpy scalar
+    arithmetic as the reference evaluates it.  defenders (P, 4) f64, evader (4,) f64 -> list of P action indices.
+    Pinned by the `action` arrays of the demon-policy traces (tests/golden/env_trace_*: steps with (t // 25) % 2 == 0)."""
+    theta_list = [i * np.pi / 4 for i in range(0, 8)]
+    actions_mat = [[np.cos(t), np.sin(t)] for t in theta_list]
+    actions_mat.append([0., 0.])
+    action_list = []
+    e_x, e_y = float(evader[0]), float(evader[1])
+    for d in np.asarray(defenders, np.float64):
+        x, y = float(d[0]), float(d[1])
+        radius = np.linalg.norm([x - e_x, y - e_y])
+        if math.isclose(radius, 0.0, abs_tol=0.01):
+            action = [0., 0.]
+        else:
+            phi = np.sign(e_y - y) * np.arccos((e_x - x) / (radius + 1e-3))
+            action = [np.cos(phi), np.sin(phi)]
+        middle_a = [np.linalg.norm((a[0] - action[0], a[1] - action[1])) for a in actions_mat]
+        action_list.append(middle_a.index(min(middle_a)))
+    return action_list
+
+
 def astar(W, H, obs_grid, start, goal):
     """obs_grid: (W+1, H+1) uint8. Returns (path[n,2] goal->start, n_expanded)."""
     obs = np.ascontiguousarray(obs_grid, np.uint8)

@@ -158,3 +158,133 @@ def test_full_size_training_iteration(name):
         moved += int(not torch.equal(p.detach(), b))
     assert moved == len(before)
     tr.env.check_status()
+
+
+# ---- BASELINE configs 4 and 5 at their sizes (configs_untested) ---------------------------------------------------
+def test_config4_env_n2n_16_pursuers_8192_envs_sampled_oracle_replay():
+    """env_n2n at BASELINE config 4's size (16 pursuers, 8192 environments): a seeded batch stepped for 40 ticks; 96 sampled
+    environments (first / last lanes of waves, first / last workgroups included) replayed in the CPU oracle -- every discrete
+    output identical, f64 state within 1e-9 -- plus whole-batch invariants."""
+    from distributed_multi_agent_reinforcement_learning_amd.n2n_env import ParticleEnv
+    from oracle import n2n_oracle as no
+    P, E, N, T = 16, 2, 8192, 40
+    env = ParticleEnv(num_envs=N, seeds=list(range(5000, 5000 + N)), episode_limit=T)
+    env.initialize(P, E)
+    env.reset()
+    p0, e0, tg = env.last_init
+    pick = np.unique(np.concatenate([np.arange(0, 8), np.arange(N - 8, N), np.linspace(0, N - 1, 80).astype(int)]))
+    cfg = no.make_cfg(P, E, T)
+    oenvs = {int(n): no.OracleN2n(cfg, p0[n], e0[n], tg[n]) for n in pick}
+    rng = np.random.default_rng(4)
+    for t in range(T):
+        acts = rng.integers(0, 9, (N, P)).astype(np.int32)
+        cmd = rng.uniform(-1, 1, (N, E))
+        env.evader_step(cmd)
+        r, done, act = env.step(acts)
+        r, done, act = r.cpu().numpy(), done.cpu().numpy(), act.cpu().numpy()
+        assert np.isfinite(r).all() and set(np.unique(act).tolist()) <= {0, 1}
+        p = env.p.permute(0, 2, 1).cpu().numpy()
+        for n, oe in oenvs.items():
+            oe.evader_step(cmd[n])
+            ro, do, ao = oe.step(acts[n])
+            assert np.array_equal(r[n], ro.astype(np.float32)) and np.array_equal(act[n], ao) and bool(done[n]) == do, (t, n)
+            assert np.max(np.abs(p[n] - oe.p)) <= 1e-9, (t, n)
+    pp = env.obs["pp_adj"]
+    assert ((pp == 0) | (pp == 1)).all() and pp.shape == (N, P, P)
+    assert done.all()                                            # episode_limit reached everywhere
+    assert (env.active_t.sum(1) < P).any()
+
+
+def test_config5_env_3d_8_pursuers_2048_envs_sampled_oracle_replay():
+    """env_3d at BASELINE config 5's size (8 pursuers, 2048 environments): as above, 64 sampled environments in the oracle."""
+    from distributed_multi_agent_reinforcement_learning_amd.e3d_env import ParticleEnv
+    from oracle import e3d_oracle as eo
+    P, N, T = 8, 2048, 50
+    env = ParticleEnv(num_envs=N, seeds=list(range(9000, 9000 + N)), max_step=T)
+    env.initialize(P)
+    env.reset()
+    p0, e0, tg = env.last_init
+    pick = np.unique(np.concatenate([np.arange(0, 8), np.arange(N - 8, N), np.linspace(0, N - 1, 48).astype(int)]))
+    cfg = eo.make_cfg(P, T)
+    oenvs = {int(n): eo.OracleE3d(cfg, p0[n], e0[n], tg[n]) for n in pick}
+    rng = np.random.default_rng(5)
+    for t in range(T):
+        acts = rng.uniform(-1, 1, (N, P, 3))
+        pe = env.e[:, None, :3].cpu().numpy() - env.p.permute(0, 2, 1)[:, :, :3].cpu().numpy()
+        chase = rng.random((N, P)) < 0.5     # half of the pursuers chase the evader so that captures / collisions happen
+        acts[..., 0] = np.where(chase, np.arctan2(pe[..., 1], pe[..., 0]) / np.pi, acts[..., 0])
+        acts[..., 1] = np.where(chase, np.arctan2(pe[..., 2], np.hypot(pe[..., 0], pe[..., 1])) / (np.pi / 2), acts[..., 1])
+        acts[..., 2] = np.where(chase, 1.0, acts[..., 2])
+        cmd = rng.uniform(-1, 1, (N, 3))
+        env.evader_step(cmd)
+        r, done, act = env.step(acts)
+        r, done, act = r.cpu().numpy(), done.cpu().numpy(), act.cpu().numpy()
+        assert np.isfinite(r).all()
+        p = env.p.permute(0, 2, 1).cpu().numpy(); e = env.e.cpu().numpy()
+        pp, pe_adj = env.obs["pp_adj"].cpu().numpy(), env.obs["pe_adj"].cpu().numpy()
+        for n, oe in oenvs.items():
+            if oe.e[0, 6] > 0 and oe.p[:, 6].sum() > 0:
+                oe.evader_step(cmd[n])
+            ro, do, ao = oe.step(acts[n])
+            assert np.array_equal(r[n], ro.astype(np.float32)) and np.array_equal(act[n], ao) and bool(done[n]) == do, (t, n)
+            assert np.max(np.abs(p[n] - oe.p)) <= 1e-9 and np.max(np.abs(e[n] - oe.e[0])) <= 1e-9, (t, n)
+            _, _, pp_o, pe_o = oe.observe()
+            assert np.array_equal(pp[n], pp_o) and np.array_equal(pe_adj[n], pe_o), (t, n)
+    assert (env.active_t.sum(1) < P).any() and (env.e[:, 6] == 0).any()
+
+
+@pytest.mark.timeout(300)
+def test_config4_shapes_training_iteration_at_1024_envs_per_rank():
+    """The stand-in for BASELINE config 4's trainer (env_n2n has no trainer in the reference): 16 defenders on 64 x 64,
+    DHGN depth 3, 1024 environments = one rank's share of 8192 over 8 GPUs; one rollout + update at that size."""
+    import math
+    from distributed_multi_agent_reinforcement_learning_amd.config import baseline_config
+    from distributed_multi_agent_reinforcement_learning_amd.trainer import Trainer
+    tr = Trainer(baseline_config("cfg4"))
+    before = [p.detach().clone() for p in tr.agent.ac_parameters]
+    steps, exp_r = tr.iterate()
+    torch.cuda.synchronize()
+    assert steps == 1024 * 150
+    buf = tr.agent.minibuffer.buffer
+    a = buf["a_n"]
+    assert a.shape == (1024, 150, 16) and a.min().item() >= 0 and a.max().item() <= 8 and torch.equal(a, a.round())
+    assert torch.isfinite(buf["r"]).all() and torch.isfinite(buf["v_n"]).all() and (buf["a_logprob_n"] <= 0).all()
+    assert ((buf["p_adj"] == 0) | (buf["p_adj"] == 1)).all()
+    assert all(math.isfinite(float(v)) for v in tr.last_log) and math.isfinite(float(exp_r))
+    for p, b in zip(tr.agent.ac_parameters, before):
+        assert torch.isfinite(p).all() and not torch.equal(p.detach(), b)
+    tr.env.check_status()
+    # 8 sampled environments of the rollout replayed in the CPU oracle from the recorded actions: the P = 16 tick (sequential
+    # step scoring) at this size produced the reference observations and rewards
+    from oracle import pe_oracle
+    # (device reset: the oracle replay needs host initial conditions, so a second, host-reset environment repeats the check)
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    cfg = baseline_config("cfg4", **{"runtime.device_reset": False})
+    env = Pursuit_Env(cfg, num_envs=1024, seeds=list(range(3000, 4024)))
+    env.reset()
+    init = env.last_init
+    pick = np.linspace(0, 1023, 8).astype(int)
+    ocfg = pe_oracle.make_config(W=64, H=64, P=16, O=cfg.map.num_max_obstacle, max_steps=150, tape_len=16)
+    oes = []
+    for n in pick:
+        oe = pe_oracle.OracleEnv(ocfg)
+        k = int(init["n_obs"][n])
+        oe.load(init["grid"][n], init["obs_xy"][n, :k], init["defenders"][n], init["evader"][n], init["target"][n], init["tape"][n])
+        oes.append(oe)
+    obs = env.observe(); env.attacker_step()
+    for oe in oes:
+        oe.observe(); oe.evader_step()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rew = torch.zeros(1024, 16, device="cuda")
+    for t in range(25):
+        a = torch.randint(0, 9, (1024, 16), dtype=torch.int32, device="cuda", generator=g)
+        env.tick(a, obs, rew)
+        an = a.cpu().numpy()
+        for n, oe in zip(pick, oes):
+            oe.step(an[n]); oe.observe(); oe.evader_step()
+    defs, eva = env.sim.defenders_aos().cpu().numpy(), env.sim.eva.cpu().numpy()
+    oadj = obs["o_adj"].cpu().numpy()
+    for n, oe in zip(pick, oes):
+        st = oe.state()
+        assert np.array_equal(defs[n], st["defenders"]) and np.array_equal(eva[n], st["evader"]), n
+        assert np.array_equal(oadj[n], oe.observe()[4]), n

@@ -109,3 +109,22 @@ def test_oracle_tables_equal_committed_constants():
     cfg = pe_oracle.make_config()
     assert [(cfg.action_u[k][0], cfg.action_u[k][1]) for k in range(9)] == tables.action_table(2.0)
     assert [(cfg.beam_dir[b][0], cfg.beam_dir[b][1]) for b in range(36)] == tables.beam_table(36)
+
+
+DEMON_TRACES = ("env_trace_20x20_p4_s0", "env_trace_20x20_p4_s2", "env_trace_40x40_p8_s0", "env_trace_40x40_p8_s2",
+                "env_trace_40x40_p8_s4")   # recorded with policy == "demon" (tests/golden/gen/make_goldens_env.py:161-168)
+
+
+def demon_steps(T):
+    return [t for t in range(T) if (t // 25) % 2 == 0]   # make_goldens_env.py:55-56
+
+
+@pytest.mark.parametrize("name", DEMON_TRACES)
+def test_demon_matches_recorded_reference_actions(name):
+    """Pursuit_Env.demon (pursuit_env.py:211-229): the oracle restatement reproduces the demon actions the reference took."""
+    d = load_trace([p for p in trace_files() if p.endswith(name + ".npz")][0])
+    n = 0
+    for t in demon_steps(d["T"]):
+        assert pe_oracle.demon(d["p_state"][t], d["e_state"][t, 0]) == [int(a) for a in d["action"][t]], t
+        n += 1
+    assert n >= 30

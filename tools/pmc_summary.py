@@ -1,6 +1,8 @@
-"""rocprofv3 --pmc csv outputs -> profiles/r02_tick_pmc.json (the record bench.py attaches as roofline.traffic).
+"""rocprofv3 --pmc csv outputs -> profiles/r03_tick_pmc.json (packed LiDAR rows: the launch the rollout issues) or, with
+--layout fp32, profiles/r03_tick_pmc_fp32.json (profile_tick.py --float-obs: the reference's fp32 rows); bench.py attaches them
+as roofline_packed_rows.traffic / roofline.traffic.
 
-  python tools/pmc_summary.py <dir-with-counter-csvs> [--us-per-launch X] [--num-envs N]
+  python tools/pmc_summary.py <dir-with-counter-csvs> [--us-per-launch X] [--num-envs N] [--layout packed|fp32]
 Looks for *counter_collection.csv files (one rocprofv3 pass each; FETCH_SIZE and WRITE_SIZE need separate passes on gfx950),
 averages every counter over the launches of the regular fused tick kernel k_tick<true, true, true, false, ...> and applies the
 gfx950 corrections of MI355X_MICROARCH.md (HBM section): FETCH_SIZE is reported in KB and counts HALF of the bytes of wide
@@ -14,6 +16,7 @@ from bench import algorithmic_bytes_per_env_step, tick_kernel_hash  # noqa: E402
 d = sys.argv[1]
 us = float(sys.argv[sys.argv.index("--us-per-launch") + 1]) if "--us-per-launch" in sys.argv else None
 N = int(sys.argv[sys.argv.index("--num-envs") + 1]) if "--num-envs" in sys.argv else 4096
+layout = sys.argv[sys.argv.index("--layout") + 1] if "--layout" in sys.argv else "packed"
 acc = {}
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -23,7 +26,8 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
         a[0] += 1; a[1] += float(r["Counter_Value"])
 avg = {k: v[1] / v[0] for k, v in acc.items()}
 n = {k: v[0] for k, v in acc.items()}
-out = {"num_envs": N, "config": "cfg2 (P=8, 40x40, O=176), packed LiDAR rows (the launch the rollout issues)",
+out = {"num_envs": N, "layout": layout,
+       "config": "cfg2 (P=8, 40x40, O=176), " + ("packed LiDAR rows (the launch the rollout issues)" if layout == "packed" else "fp32 (N, P, O) LiDAR rows (reference layout)"),
        "kernel": "k_tick<true, true, true, false, true>", "kernel_hash": tick_kernel_hash(), "launches_sampled": n,
        "counters_avg_per_launch": {k: round(v, 2) for k, v in sorted(avg.items())},
        "algorithmic_bytes_per_launch": N * algorithmic_bytes_per_env_step(8, 40, 40, 176), "us_per_launch": us,
@@ -33,5 +37,5 @@ if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     out["fetch_bytes_corrected_x2"] = int(avg["FETCH_SIZE"] * 1024 * 2)
     out["write_bytes"] = int(avg["WRITE_SIZE"] * 1024)
     out["traffic_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_bytes"]
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_tick_pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r03_tick_pmc.json" if layout == "packed" else "r03_tick_pmc_fp32.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
