@@ -112,6 +112,8 @@ class ParticleEnv:
         self.done_t = torch.zeros((N,), dtype=torch.uint8, device=dev)
         s = np.ascontiguousarray(self.seeds, np.uint32)
         self.resetter = self.L.e3d_resetter_create(C.byref(c), N, s.ctypes.data_as(C.c_void_p))
+        if not self.resetter:
+            raise RuntimeError("e3d_resetter_create failed (bad configuration or out of memory)")
         self._obs_struct = E3dObsOut()
         for k, t in self.obs.items():
             setattr(self._obs_struct, k, t.data_ptr())

@@ -38,7 +38,10 @@ class _Buffer(dict):
 class ReplayBuffer:
     """Zero-padded episode buffer with the reference's keys and (N, T, ...) layouts (DHGN/replay_buffer.py:24-40),
     resident in HBM.  `o_state` is stored once per episode as (N, O, 4) (`o_static`) and exposed in the reference's
-    (N, T, O, 4) shape as a broadcast view."""
+    (N, T, O, 4) shape as a broadcast view.
+    Deviation at `algo.depth: 0` only: `actor_historical_embedding` / `critic_historical_embedding` are allocated with the
+    reference's shape but left ZERO by the rollout unless `runtime.record_unused_embeddings` is true -- the update reads them as
+    FCRA history only, which does not exist at depth 0 (the reference records them regardless and never reads them there)."""
 
     def __init__(self, cfg, num_rows=None, device=None):
         self.episode_limit = cfg.env.max_steps
@@ -163,6 +166,9 @@ class MAPPO:
         # Trainer / Worker before the first rollout; the counter itself is part of the resume bundle.
         self.sample_rank = int(rt.get("sample_rank", 0))
         self.use_graphs = bool(rt.get("use_graphs", True))
+        # depth 0: nothing reads buffer["{actor,critic}_historical_embedding"], so the rollout does not fill them (they stay zero;
+        # the reference stores every tick's embedding regardless, DHGN/mappo_parallel.py:795-798).  true = record them anyway.
+        self.record_unused_embeddings = bool(rt.get("record_unused_embeddings", False))
         self.last_adv = self.last_v_target = None
 
     # ---- update (:638-723) ------------------------------------------------------------------------------------
@@ -265,7 +271,7 @@ class MAPPO:
                 st.policy_step()
             items += [(st.v, buf["v_n"][rows, t]), (st.a_n, buf["a_n"][rows, t]),      # int32 -> float32 like the reference buffer
                       (st.logp, buf["a_logprob_n"][rows, t])]
-            if d:  # the update reads the stored embeddings as FCRA history only (EmbeddingDataset2, :95-113): nothing to keep at depth 0
+            if d or self.record_unused_embeddings:  # the update reads the stored embeddings as FCRA history only (EmbeddingDataset2, :95-113)
                 items += [(st.a_cur, buf["actor_historical_embedding"][rows, t + d]), (st.c_cur, buf["critic_historical_embedding"][rows, t + d])]
             # one launch records the tick (and adds the previous tick's raw reward to the episode return)
             ops.rollout_record(items, raw if t > 0 else None, episode_reward)
@@ -368,9 +374,10 @@ class _RolloutState:
             feat_c, hc = ag.critic._rollout_features(c_emb, self.hc, True)
             v = ag.critic.head(feat_c, out=self.v)            # the value lands in the static storage
             w_a = ag.actor.head_weight() if forced_actions is None else None
-            if w_a is not None and feat_a.shape[-1] == ops.HEAD_FEATURES and w_a.shape[0] <= ops.HEAD_MAX_OUT:
+            feat_a = feat_a.contiguous()
+            if w_a is not None and ops._head_ok(feat_a, w_a, ag.actor.Mean.bias):
                 # action head, softmax, sample, log-probability and the stream counter in one launch
-                ops.head_sample(feat_a.contiguous(), w_a, ag.actor.Mean.bias, ag.sample_seed, self.counter, self.ticket, (self.a_n, self.logp))
+                ops.head_sample(feat_a, w_a, ag.actor.Mean.bias, ag.sample_seed, self.counter, self.ticket, (self.a_n, self.logp))
                 prob = None
             else:
                 prob = torch.softmax(ag.actor.head(feat_a), dim=-1)
@@ -419,7 +426,7 @@ class _RolloutState:
                 self.policy_step()
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # a background evaluator may launch on its own stream meanwhile
             self.policy_step()
         for t, k in zip((self.ha, self.hc, self.hist, self.a_cur, self.c_cur, self.counter, self.a_n, self.logp, self.v), keep):
             t.copy_(k)

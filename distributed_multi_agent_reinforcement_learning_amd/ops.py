@@ -414,7 +414,8 @@ HEAD_MAX_OUT, HEAD_FEATURES = 16, 128
 
 def _head_ok(feat, W, b):
     return (feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous() and W.shape[1] == HEAD_FEATURES and feat.shape[-1] == HEAD_FEATURES
-            and W.shape[0] <= HEAD_MAX_OUT and b is not None and not torch.is_grad_enabled())
+            and W.shape[0] <= HEAD_MAX_OUT and b is not None and not torch.is_grad_enabled()
+            and feat.data_ptr() % 16 == 0)   # the kernel reads feature rows with 16-byte loads (an offset view falls back to F.linear)
 
 
 def head_linear(feat, W, b, out=None):

@@ -199,26 +199,56 @@ class Trainer:
         return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
 
 
-def train_agent_multiprocessing(cfg, max_iterations=None, num_eval_envs=16, eval_every=1):
-    """main.py:41-172 on the Trainer: runs until the evaluator says stop (total_step > max_train_steps)."""
+def _device_weights(module):
+    """snapshot of a module's state_dict on its device (no host round trip); the evaluator loads it on its own stream"""
+    return {k: v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def train_agent_multiprocessing(cfg, max_iterations=None, num_eval_envs=16, eval_every=1, async_eval=None):
+    """main.py:41-172 on the Trainer: runs until the evaluator says stop (total_step > max_train_steps).
+
+    Evaluation is asynchronous like the reference's (main.py:135-158: `evaluator.run.remote(...)`, polled with `ray.wait(...,
+    timeout=0.1)` while training goes on): the evaluator is a background actor of ray_shim -- its own host thread and HIP stream on
+    rank 0's GPU -- that works on a device-side snapshot of the weights; the training loop only collects a finished evaluation and
+    starts the next one with the current weights, it never waits for one.  No rank sits in a collective for the length of an
+    evaluation: the per-iteration flag broadcast carries whatever verdict rank 0 holds at that moment.
+    `runtime.async_eval: false` (or async_eval=False) evaluates inline on rank 0 (deterministic recorder rows per iteration)."""
+    from . import ray_shim
     tr = Trainer(cfg)
-    evaluator = EvaluatorProc(cfg, num_eval_envs) if tr.rank == 0 else None
+    if async_eval is None:
+        async_eval = bool(cfg.runtime.get("async_eval", True))
+    evaluator = None
+    if tr.rank == 0:
+        evaluator = ray_shim.remote(EvaluatorProc).options(background=bool(async_eval)).remote(cfg, num_eval_envs)
     cwd = cfg.algo.save_cwd
     if_train = True
+    eval_run_ref = None
+
+    def collect(obj):
+        """main.py:139-156: the evaluator's verdict, and the checkpoint when the greedy return did not get worse"""
+        ok, ref_list = obj[0], obj[1]
+        if len(ref_list) > 0:
+            actor, critic, recorder = (ray_shim.get(r) for r in ref_list)
+            os.makedirs(cwd, exist_ok=True)
+            np.save(cwd + "/recorder.npy", recorder)
+            draw_learning_curve(recorder=np.array(recorder), cwd=cwd)
+            save_checkpoint(actor, critic, cwd)
+        return ok
+
     while if_train:
         t0 = time.time()
         steps, exp_r = tr.iterate()
         if tr.rank == 0:
             print(f"iteration {tr.iteration}: {steps} env-steps in {time.time() - t0:.2f}s")
             if tr.iteration % eval_every == 0:
-                aw, cw = tr.agent.actor.get_weights(), tr.agent.critic.get_weights()
-                if_train, ref_list = evaluator.run(aw, cw, tr.total_steps, exp_r, tr.last_log)
-                if ref_list:
-                    actor, critic, recorder = ref_list
-                    os.makedirs(cwd, exist_ok=True)
-                    np.save(cwd + "/recorder.npy", recorder)
-                    draw_learning_curve(recorder=np.array(recorder), cwd=cwd)
-                    save_checkpoint(actor, critic, cwd)
+                if eval_run_ref is not None:
+                    done, _ = ray_shim.wait([eval_run_ref], num_returns=1, timeout=0 if async_eval else None)
+                    if done:
+                        if_train = collect(ray_shim.get(done[0]))
+                        eval_run_ref = None
+                if eval_run_ref is None and if_train:
+                    eval_run_ref = evaluator.run.remote(_device_weights(tr.agent.actor), _device_weights(tr.agent.critic), tr.total_steps, exp_r,
+                                                        tr.last_log)
         if tr.world > 1:
             flag = torch.tensor([1 if if_train else 0], device=tr.device if dist.get_backend() != "gloo" else "cpu")
             dist.broadcast(flag, src=0)
@@ -226,6 +256,9 @@ def train_agent_multiprocessing(cfg, max_iterations=None, num_eval_envs=16, eval
         if max_iterations is not None and tr.iteration >= max_iterations:
             break
     if tr.rank == 0:
+        if eval_run_ref is not None:   # the evaluation still in flight belongs to the run's record
+            collect(ray_shim.get(eval_run_ref))
         save_checkpoint(tr.agent.actor, tr.agent.critic, cwd, "_final")
-        np.save(cwd + "/recorder.npy", evaluator.get_recorder())
+        np.save(cwd + "/recorder.npy", ray_shim.get(evaluator.get_recorder.remote()))
+        evaluator._shutdown()
     return tr

@@ -309,3 +309,24 @@ def test_mlp_ablation_bypasses_the_gru():
     assert any(np.any(g) for n, g in zip(names, ag) if n.startswith("Mean."))
     agent.ac_optimizer.step()
     assert not torch.equal(before, agent.actor.Mean.weight)
+
+
+def test_depth0_buffer_embeddings_are_zero_unless_recording_is_requested():
+    """at depth 0 the rollout leaves buffer['{actor,critic}_historical_embedding'] zero (nothing reads them; documented in
+    ReplayBuffer) -- `runtime.record_unused_embeddings: true` restores the reference's unconditional recording
+    (DHGN/mappo_parallel.py:795-798), with identical actions / values either way."""
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import MAPPO
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from tests.helpers import product_cfg
+    bufs = []
+    for rec in (False, True):
+        cfg = product_cfg(8, 40, 40, T=10, depth=0, **{"runtime.seed": 9, "runtime.record_unused_embeddings": rec})
+        torch.manual_seed(6)
+        agent = MAPPO(cfg, 6, 3, "Worker")
+        exp_r, rb, steps = agent.explore_env(Pursuit_Env(cfg, num_envs=6), 1)
+        bufs.append({k: v.clone() for k, v in rb.buffer.items() if k != "o_state"})
+    for k in ("actor_historical_embedding", "critic_historical_embedding"):
+        assert bufs[0][k].shape == (6, 10, 8, 128) and not bufs[0][k].any()
+        assert bufs[1][k].abs().sum() > 0 and bufs[1][k][:, 0].abs().sum() > 0
+    for k in ("a_n", "v_n", "a_logprob_n", "r", "p_state"):
+        assert torch.equal(bufs[0][k], bufs[1][k]), k

@@ -215,3 +215,78 @@ def test_ranks_draw_independent_exploration_noise(tmp_path):
     a1, _ = ops.categorical_sample(prob, 7, 0, counter=states[1].counter.clone())
     legacy, _ = ops.categorical_sample(prob, 7, 0)
     assert torch.equal(a0, legacy) and (a0 != a1).float().mean() > 0.8
+
+
+@pytest.mark.timeout(300)
+def test_ray_style_driver_on_the_shim_with_a_background_evaluator(tmp_path):
+    """The constructs of the reference's driver (main.py:55-158: `.options(...).remote(...)`, `method.remote(...)`, `ray.get`,
+    `ray.wait(..., timeout)`, refs passed as arguments, a non-blocking evaluator) on the real Learner / Worker / EvaluatorProc
+    through ray_shim; the evaluator is a background actor (own thread + stream) working on a snapshot while training goes on.
+    (The reference's loop text itself runs on the shim in tests/test_ray_shim.py, where the reference tree exists.)"""
+    import time
+    import distributed_multi_agent_reinforcement_learning_amd.ray_shim as ray
+    from distributed_multi_agent_reinforcement_learning_amd import evaluator as ev_mod, runner
+    cfg = small_cfg(tmp_path)
+    Learner, Worker, EvaluatorProc = ray.remote(runner.Learner), ray.remote(runner.Worker), ray.remote(ev_mod.EvaluatorProc)
+    torch.manual_seed(0)
+    learners = [Learner.options(resources={f"node_{n}": 0.001}).remote(cfg, 8, 4, n) for n in range(2)]
+    workers = [[Worker.options(resources={f"node_{n}": 0.001}).remote(n, cfg, num_envs=8)] for n in range(2)]
+    evaluator = EvaluatorProc.options(resources={"node_-1": 0.001}, background=True).remote(cfg, 4)
+    actor_weights, critic_weights = ray.get(learners[0].get_weights.remote())
+    for lr in learners:
+        lr.set_weights.remote(actor_weights, critic_weights)
+    total_steps, eval_run_ref, finished, if_train = 0, None, [], True
+    for it in range(3):
+        worker_run_ref = [[w.run.remote(actor_weights, critic_weights) for w in workers[n]] for n in range(2)]
+        learner_run_ref = [learners[n].collect_buffer.remote(worker_run_ref[n]) for n in range(2)]   # a list of refs as an argument
+        exp_r = 0.0
+        while len(learner_run_ref) > 0:
+            ret, learner_run_ref = ray.wait(learner_run_ref, num_returns=1, timeout=0.1)
+            if len(ret) > 0:
+                r, steps = ray.get(ret)[0]
+                exp_r += r / 2
+                total_steps += steps
+        grads = ray.get([lr.compute_and_get_gradients.remote(total_steps) for lr in learners])
+        a_sum = [np.stack(g).sum(axis=0) for g in zip(*[g[1] for g in grads])]
+        c_sum = [np.stack(g).sum(axis=0) for g in zip(*[g[2] for g in grads])]
+        for lr in learners:
+            lr.set_gradients_and_update.remote(a_sum, c_sum, total_steps)
+        actor_weights, critic_weights = ray.get(learners[0].get_weights.remote())
+        if eval_run_ref is None:
+            t0 = time.monotonic()
+            eval_run_ref = [evaluator.run.remote(actor_weights, critic_weights, total_steps, exp_r, grads[0][0])]
+            assert time.monotonic() - t0 < 0.5                       # returns at once: the evaluation runs beside the loop
+        else:
+            return_ref, eval_run_ref = ray.wait(object_refs=eval_run_ref, num_returns=1, timeout=0.1)
+            if len(return_ref):
+                obj = ray.get(return_ref)[0]
+                if_train, ref_list = obj[0], obj[1]
+                finished.append(obj)
+                if len(ref_list) > 0:
+                    actor = ray.get(ref_list[0])
+                    assert hasattr(actor, "shared_net") and hasattr(actor, "GRU") and hasattr(actor, "Mean")
+                eval_run_ref = [evaluator.run.remote(actor_weights, critic_weights, total_steps, exp_r, grads[0][0])]
+    assert total_steps == 3 * 2 * 8 * 10
+    last = ray.get(eval_run_ref)[0]
+    recorder = ray.get(evaluator.get_recorder.remote())
+    assert len(recorder) == len(finished) + 1 >= 1 and len(recorder[0]) == 6 and last[0] in (True, False)
+    assert all(np.isfinite(row).all() for row in np.asarray(recorder, np.float64))
+    w0, w1 = ray.get(learners[0].get_weights.remote()), ray.get(learners[1].get_weights.remote())
+    for k in w0[0]:
+        assert torch.equal(w0[0][k], w1[0][k]), k
+    evaluator._shutdown()
+
+
+def test_async_and_inline_evaluation_record_the_same_first_row(tmp_path):
+    """trainer.train_agent_multiprocessing with the background evaluator (default) and with runtime.async_eval = false: same
+    training (the evaluator only reads snapshots), the first recorder row -- evaluation of the weights after iteration 1 -- equal."""
+    from distributed_multi_agent_reinforcement_learning_amd import trainer
+    recs = []
+    for mode in (True, False):
+        cfg = small_cfg(tmp_path / ("a" if mode else "b"), **{"runtime.async_eval": mode})
+        tr = trainer.train_agent_multiprocessing(cfg, max_iterations=3, num_eval_envs=4)
+        recs.append((np.load(cfg.algo.save_cwd + "/recorder.npy"), [p.detach().clone() for p in tr.agent.ac_parameters]))
+    assert len(recs[1][0]) == 3 and 1 <= len(recs[0][0]) <= 3
+    assert np.allclose(recs[0][0][0], recs[1][0][0], rtol=1e-5, atol=1e-6), (recs[0][0][0], recs[1][0][0])
+    for p, q in zip(recs[0][1], recs[1][1]):
+        assert torch.equal(p, q)
