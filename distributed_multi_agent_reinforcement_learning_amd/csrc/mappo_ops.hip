@@ -947,6 +947,17 @@ __global__ __launch_bounds__(256) void k_head(int R, int A, const float *__restr
     }
 }
 
+// Workgroup barrier for kernels whose waves exchange data through LDS only.  __syncthreads() is a workgroup-scope release +
+// acquire around s_barrier, and the release makes every wave wait for ALL its outstanding memory operations (s_waitcnt vmcnt(0)):
+// in the persistent GRU kernels that drained 40-80 KB of freshly issued global stores per step at ~10 B/clk/CU before any wave
+// could start the next step's MFMAs (1.7 of 4.6 us per step).  Here a wave waits for its own LDS operations only; global loads
+// and stores stay in flight across the barrier and complete under the next matrix phase.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---- GRU gate math (torch.nn.GRU cell; reference DHGN/mappo_parallel.py:397,424,434) ------------------------------
 // gi = x W_ih^T + b_ih and gh = h W_hh^T come from MFMA GEMMs (rocBLAS/hipBLASLt fp32); everything between them and
 // the next step's GEMM is fused here: bias, sigmoid/tanh, the state update and (for training) the saved gates.
@@ -1018,14 +1029,11 @@ __global__ void k_gru_gates_bwd(int B, int H, const float *dout, const float *dc
 // ---- persistent GRU over a whole sequence (H = 128) ---------------------------------------------------------------
 // The recurrence h_t = cell(gi_t, h_{t-1}) is latency bound when every step is a GEMM launch plus a gate launch
 // (2 x 150 launches per layer, ~27 us per step at 3280 rows).  Here one workgroup (8 wavefronts) owns 16 batch rows for
-// all T steps: W_hh (384 x 128 fp32 = 196 KB, more than LDS) lives in the workgroup's REGISTERS -- wave w holds the
-// r/z/n rows of hidden units 16w..16w+15 as v_mfma_f32_16x16x4_f32 B-operands (96 VGPRs) -- the h tile lives in LDS in
-// A-operand order, the three gate tiles of a hidden unit land in the same lane (C layout: col = lane & 15,
-// row = 4 (lane >> 4) + reg), so the gate math needs no exchange and there is one barrier per step.
-constexpr int GRU_H = 128, GRU_RB = 16, GRU_LD = 36;  // LD: 32 k-groups + 4 pad floats (bank spread for ds_read_b128)
+// all T steps: W_hh (384 x 128 fp32 = 196 KB, more than LDS) lives in the workgroup's REGISTERS as v_mfma_f32_16x16x4_f32
+// operands (96 VGPRs per lane), the h tile lives in LDS in operand order, the three gate tiles of a hidden unit land in the same
+// lane, so the gate math needs no exchange and there is one barrier per step.  Kernels: k_gru_seq_fwd2 / k_gru_seq_bwd2 below.
+constexpr int GRU_H = 128, GRU_RB = 16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int gru_hidx(int row, int k) { return ((k & 3) * GRU_RB + row) * GRU_LD + (k >> 2); }
 
 // gi_agents: row order of gi (and of dgi in the backward kernel).  0: time-major [t][b] like out.  P > 0: the rows of the
 // encoder's output, (episode n, step t, agent p) with b = n P + p, i.e. row ((b / P) T + t) P + b % P -- the input projection
@@ -1033,76 +1041,6 @@ __device__ __forceinline__ int gru_hidx(int row, int k) { return ((k & 3) * GRU_
 // tensors autograd would make around the GRU (reference _sequence_features, DHGN/mappo_parallel.py:426-437) do not exist.
 __device__ __forceinline__ size_t gru_gi_row(int b, int t, int T, int B, int gi_agents) {
     return gi_agents ? ((size_t)(b / gi_agents) * T + t) * gi_agents + b % gi_agents : (size_t)t * B + b;
-}
-
-__global__ __launch_bounds__(512) void k_gru_seq_fwd(int T, int B, const float *gi, const float *w_hh, const float *b_hh, const float *h0,
-                                                     float *out, float *save, int gi_agents) {
-    __shared__ __attribute__((aligned(16))) float hs[2][4 * GRU_RB * GRU_LD];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int b0 = blockIdx.x * GRU_RB;
-    const int c16 = l & 15, q = l >> 4;
-    const int j = 16 * w + c16;  // hidden unit of this lane's C columns
-    float wr[32], wz[32], wn[32];
-#pragma unroll
-    for (int kk = 0; kk < 32; kk++) {
-        wr[kk] = w_hh[(size_t)(j) * GRU_H + 4 * kk + q];
-        wz[kk] = w_hh[(size_t)(GRU_H + j) * GRU_H + 4 * kk + q];
-        wn[kk] = w_hh[(size_t)(2 * GRU_H + j) * GRU_H + 4 * kk + q];
-    }
-    const float br = b_hh[j], bz = b_hh[GRU_H + j], bn = b_hh[2 * GRU_H + j];
-    for (int e = tid; e < GRU_RB * GRU_H; e += 512) {
-        const int row = e >> 7, k = e & 127;
-        hs[0][gru_hidx(row, k)] = (b0 + row < B) ? h0[(size_t)(b0 + row) * GRU_H + k] : 0.f;
-    }
-    __syncthreads();
-    int cur = 0;
-    const size_t BH = (size_t)B * GRU_H;
-    for (int t = 0; t < T; t++) {
-        float gir[4], giz[4], gin[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int row = 4 * q + reg;
-            gir[reg] = giz[reg] = gin[reg] = 0.f;
-            if (b0 + row < B) {
-                const float *g = gi + gru_gi_row(b0 + row, t, T, B, gi_agents) * 3 * GRU_H;
-                gir[reg] = g[j]; giz[reg] = g[GRU_H + j]; gin[reg] = g[2 * GRU_H + j];
-            }
-        }
-        const float *hp = &hs[cur][(q * GRU_RB + c16) * GRU_LD];  // A operand: row = lane & 15, k = 4 kk + (lane >> 4)
-        f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
-#pragma unroll
-        for (int k4 = 0; k4 < 8; k4++) {
-            const f32x4 a = *(const f32x4 *)(hp + 4 * k4);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], wr[4 * k4 + u], ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], wz[4 * k4 + u], az, 0, 0, 0);
-                an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], wn[4 * k4 + u], an, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int row = 4 * q + reg;
-            const int hi = gru_hidx(row, j);
-            const float hprev = hs[cur][hi];
-            const float r = sigmoid_hw(gir[reg] + ar[reg] + br);
-            const float z = sigmoid_hw(giz[reg] + az[reg] + bz);
-            const float hn = an[reg] + bn;
-            const float n = tanh_hw(gin[reg] + r * hn);
-            const float hnew = (1.f - z) * n + z * hprev;
-            hs[cur ^ 1][hi] = hnew;
-            if (b0 + row < B) {
-                const size_t o = (size_t)(b0 + row) * GRU_H + j;
-                out[(size_t)t * BH + o] = hnew;
-                if (save) {
-                    float *sv = save + (size_t)t * 4 * BH;
-                    sv[o] = r; sv[BH + o] = z; sv[2 * BH + o] = n; sv[3 * BH + o] = hn;
-                }
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
 }
 
 // ---- one GRU step for a large batch (the rollout: B = envs x agents rows, T = 1) ---------------------------------------
@@ -1164,7 +1102,7 @@ __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, const float *
     }
 #define GRU_STAGE(buf) { *(float4 *)&xs[buf][sidx] = px; *(float4 *)&hs[buf][sidx] = ph; }
     if (blk < nblk) { GRU_FETCH(blk) GRU_STAGE(0) }
-    __syncthreads();
+    lds_barrier();
     int cur = 0;
     for (; blk < nblk; blk += gridDim.x) {
         const int nxt = blk + gridDim.x;
@@ -1220,104 +1158,205 @@ __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, const float *
             if (blk * GRU_RB + row < B) hout[(size_t)(blk * GRU_RB + row) * GRU_H + j] = (1.f - z) * n + z * hpv;
         }
         if (nxt < nblk) GRU_STAGE(cur ^ 1)  // the other buffer: its last readers passed the barrier of the previous tile
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
 #undef GRU_FETCH
 #undef GRU_STAGE
 }
 
-// backward of the sequence: dgi, dgh [T][B][3H] for the later weight-gradient GEMMs, dh0 [B][H].
-// dL/dh_{t-1} = dh_t z_t + dgh_t W_hh : the (16 x 384) dgh tile goes through LDS in A-operand order, W_hh columns
-// 16w..16w+15 are the B-operand of wave w (96 VGPRs), and the result lands in the lane that owns that (row, hidden unit).
-constexpr int GRU_LD3 = 100;  // 96 k-groups + 4 pad
-__device__ __forceinline__ int gru_gidx(int row, int k) { return ((k & 3) * GRU_RB + row) * GRU_LD3 + (k >> 2); }
+// ---- the sequence kernels: TRANSPOSED tiles ------------------------------------------------------------------------------------
+// A = weights, B = the h / dgh tile, so the MFMA result is gate^T: a lane owns FOUR CONSECUTIVE hidden units of ONE batch row
+// (rounds 1-2 computed gate[row][unit] tiles: one unit of four rows per lane, every global access a scalar in its own 64-byte
+// segment, 32 / 48 vector-memory instructions per lane and step).  gi / out / dout / dgi move as 16-byte accesses (3 + 1 + 4 in the
+// forward step), the h tile is read and written with one ds_read_b128 / ds_write_b128 per lane, and the saved gates -- private to
+// this kernel pair -- are stored in lane order (save[t][block][plane][thread] float4: 1 KB contiguous per wave instruction).  The
+// contraction index is permuted so that a lane's four units are contiguous in the operand tile as well: MFMA step s of lane
+// group q takes k = 32 q + s (forward; 96 q + s in the backward product over the 384 gate columns), k_gru_cell's bijection.
+// Backward: dr and dz are no longer stored twice.  With time-major dgi rows (gi_agents == 0) the kernel writes dgi = (dr, dz, dn)
+// and a separate dnr [T][B][H]; dW_hh = [dr dz | dnr]^T h_prev then takes its first 256 rows from dgi and the last 128 from dnr
+// (-0.5 GB of stores per call, 859 -> 739 us).  With the encoder's row order (gi_agents > 0: dgi and h_prev rows do not line up)
+// the full dgh = (dr, dz, dnr) is still written.  The gate-gradient tile is double buffered: one barrier per step instead of two.
+// What bounds them (tools/microbench/gru_step_lab.hip, s_memtime stamps per wave): per step and SIMD the two waves
+// issue 2 x 96 MFMAs = 6 144 pipe cycles; the older wave's gate math hides under the younger's MFMAs, the younger's (~860 cycles),
+// the store issue (~500) and the first operand fetch after the barrier (~230) do not: 8 470 cycles per step with memory traffic,
+// 7 660 without.  The instruction count of the memory phase and the barrier flavour do not move the time; bytes do (~80 us / GB).
+constexpr int GRU2_LD = 36, GRU2_LD3 = 100;   // floats per (plane, row): 32 (96) operand slots + 4 pad, rows stay 16-byte aligned
+__device__ __forceinline__ int gru2_hidx(int row, int k) { return ((k >> 5) * GRU_RB + row) * GRU2_LD + (k & 31); }
 
-__global__ __launch_bounds__(512) void k_gru_seq_bwd(int T, int B, const float *dout, const float *save, const float *out, const float *h0,
-                                                     const float *w_hh, float *dgi, float *dgh, float *dh0, float *bias_partials, int gi_agents) {
-    __shared__ __attribute__((aligned(16))) float gs[4 * GRU_RB * GRU_LD3];
-    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;  // column sums of dgi / dgh over this workgroup's rows and all steps
+__global__ __launch_bounds__(512) void k_gru_seq_fwd2(int T, int B, const float *__restrict__ gi, const float *__restrict__ w_hh,
+                                                      const float *__restrict__ b_hh, const float *__restrict__ h0, float *__restrict__ out,
+                                                      float *__restrict__ save, int gi_agents) {
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * GRU_RB * GRU2_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int b0 = blockIdx.x * GRU_RB;
     const int c16 = l & 15, q = l >> 4;
-    const int j = 16 * w + c16;
+    // A operand: lane (m = c16, k-group q) holds W[gate][16 w + c16][32 q + s], s = 0..31 -- 128 contiguous bytes per gate
+    float wr[32], wz[32], wn[32];
+#define GRU2_LOAD_W(dst, gate)                                                                              \
+    {                                                                                                       \
+        const float4 *src = (const float4 *)(w_hh + (size_t)((gate) * GRU_H + 16 * w + c16) * GRU_H + 32 * q); \
+        _Pragma("unroll") for (int i = 0; i < 8; i++) {                                                     \
+            const float4 v = src[i];                                                                        \
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;              \
+        }                                                                                                   \
+    }
+    GRU2_LOAD_W(wr, 0) GRU2_LOAD_W(wz, 1) GRU2_LOAD_W(wn, 2)
+#undef GRU2_LOAD_W
+    // D^T tile: this lane owns batch row c16, hidden units u0 .. u0 + 3
+    const int u0 = 16 * w + 4 * q, row = c16;
+    const bool live = b0 + row < B;
+    const float4 br = *(const float4 *)(b_hh + u0), bz = *(const float4 *)(b_hh + GRU_H + u0), bn = *(const float4 *)(b_hh + 2 * GRU_H + u0);
+    {
+        const int srow = tid >> 5, sk = (tid & 31) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b0 + srow < B) v = *(const float4 *)(h0 + (size_t)(b0 + srow) * GRU_H + sk);
+        *(float4 *)&hs[0][gru2_hidx(srow, sk)] = v;
+    }
+    lds_barrier();
+    const int hpos = gru2_hidx(row, u0);
+    const size_t nblk = gridDim.x;
+    float4 *sv = save ? (float4 *)save + (size_t)blockIdx.x * 4 * 512 + tid : nullptr;
+    int cur = 0;
+    for (int t = 0; t < T; t++) {
+        float4 gr = make_float4(0.f, 0.f, 0.f, 0.f), gz = gr, gn = gr;
+        if (live) {
+            const float *g = gi + gru_gi_row(b0 + row, t, T, B, gi_agents) * 3 * GRU_H + u0;
+            gr = *(const float4 *)g; gz = *(const float4 *)(g + GRU_H); gn = *(const float4 *)(g + 2 * GRU_H);
+        }
+        const float *hp = &hs[cur][(q * GRU_RB + c16) * GRU2_LD];   // B operand: h[row c16][32 q + s]
+        f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; k4++) {
+            const f32x4 a = *(const f32x4 *)(hp + 4 * k4);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[4 * k4 + u], a[u], ar, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[4 * k4 + u], a[u], az, 0, 0, 0);
+                an = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[4 * k4 + u], a[u], an, 0, 0, 0);
+            }
+        }
+        const float4 hprev = *(const float4 *)&hs[cur][hpos];
+        float4 r, z, hn, n, hnew;
+#define GRU2_ONE(f, i)                                   \
+        r.f = sigmoid_hw(gr.f + ar[i] + br.f);           \
+        z.f = sigmoid_hw(gz.f + az[i] + bz.f);           \
+        hn.f = an[i] + bn.f;                             \
+        n.f = tanh_hw(gn.f + r.f * hn.f);                \
+        hnew.f = (1.f - z.f) * n.f + z.f * hprev.f;
+        GRU2_ONE(x, 0) GRU2_ONE(y, 1) GRU2_ONE(z, 2) GRU2_ONE(w, 3)
+#undef GRU2_ONE
+        *(float4 *)&hs[cur ^ 1][hpos] = hnew;
+        if (live) *(float4 *)(out + ((size_t)t * B + b0 + row) * GRU_H + u0) = hnew;
+        if (sv) {   // lane order; rows past B are padding of the (opaque) save area
+            float4 *s4 = sv + (size_t)t * nblk * 4 * 512;
+            s4[0] = r; s4[512] = z; s4[1024] = n; s4[1536] = hn;
+        }
+        lds_barrier();
+        cur ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_gru_seq_bwd2(int T, int B, const float *__restrict__ dout, const float *__restrict__ save,
+                                                      const float *__restrict__ out, const float *__restrict__ h0, const float *__restrict__ w_hh,
+                                                      float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dnr_out,
+                                                      float *__restrict__ dh0, float *__restrict__ bias_partials, int gi_agents) {
+    __shared__ __attribute__((aligned(16))) float gs[2][4 * GRU_RB * GRU2_LD3];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int b0 = blockIdx.x * GRU_RB;
+    const int c16 = l & 15, q = l >> 4;
+    // A operand = W_hh^T tile: lane (m = c16, k-group q) holds W_hh[96 q + s][16 w + c16], s = 0..95
     float wb[96];
 #pragma unroll
-    for (int kk = 0; kk < 96; kk++) wb[kk] = w_hh[(size_t)(4 * kk + q) * GRU_H + j];  // B[k][n = j]
-    const size_t BH = (size_t)B * GRU_H;
-    float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
-    // The saved gates, h_{t-1} and dout of a step do not depend on the recurrence: they are loaded one step ahead (24
-    // registers), so their HBM latency hides behind the MFMA phase instead of stalling the head of every step.
-    float pr[4], pz[4], pn[4], phn[4], php[4], pdo[4];
-    auto prefetch = [&](int t) {
+    for (int s = 0; s < 96; s++) wb[s] = w_hh[(size_t)(96 * q + s) * GRU_H + 16 * w + c16];
+    const int u0 = 16 * w + 4 * q, row = c16;
+    const bool live = b0 + row < B;
+    // where this lane's (dr, dz, dnr) quads go in the operand tile: gate column k0 = 128 g + u0 -> plane k0 / 96, slot k0 % 96
+    int gpos[3];
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int row = 4 * q + reg;
-            pr[reg] = pz[reg] = pn[reg] = phn[reg] = php[reg] = pdo[reg] = 0.f;
-            if (b0 + row < B) {
-                const size_t o = (size_t)(b0 + row) * GRU_H + j;
-                const float *sv = save + (size_t)t * 4 * BH;
-                pr[reg] = sv[o]; pz[reg] = sv[BH + o]; pn[reg] = sv[2 * BH + o]; phn[reg] = sv[3 * BH + o];
-                php[reg] = t > 0 ? out[(size_t)(t - 1) * BH + o] : h0[o];
-                pdo[reg] = dout[(size_t)t * BH + o];
-            }
+    for (int g = 0; g < 3; g++) {
+        const int k0 = GRU_H * g + u0;
+        gpos[g] = ((k0 / 96) * GRU_RB + row) * GRU2_LD3 + k0 % 96;
+    }
+    const size_t nblk = gridDim.x;
+    const float4 *sv = (const float4 *)save + (size_t)blockIdx.x * 4 * 512 + tid;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sb_r = zero4, sb_z = zero4, sb_n = zero4, sb_nr = zero4;
+    float4 dcarry = zero4;
+    float4 pr, pz, pn, phn, php, pdo;   // one step ahead: none of them depends on the recurrence
+    auto prefetch = [&](int t) {
+        pr = pz = pn = phn = php = pdo = zero4;
+        if (live) {
+            const float4 *s4 = sv + (size_t)t * nblk * 4 * 512;
+            pr = s4[0]; pz = s4[512]; pn = s4[1024]; phn = s4[1536];
+            const size_t o = (size_t)(b0 + row) * GRU_H + u0;
+            php = *(const float4 *)(t > 0 ? out + (size_t)(t - 1) * B * GRU_H + o : h0 + o);
+            pdo = *(const float4 *)(dout + (size_t)t * B * GRU_H + o);
         }
     };
     prefetch(T - 1);
+    int buf = 0;
     for (int t = T - 1; t >= 0; t--) {
-        float dhz[4], cr[4], cz[4], cn[4], chn[4], chp[4], cdo[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) { cr[reg] = pr[reg]; cz[reg] = pz[reg]; cn[reg] = pn[reg]; chn[reg] = phn[reg]; chp[reg] = php[reg]; cdo[reg] = pdo[reg]; }
+        const float4 r = pr, z = pz, n = pn, hn = phn, hp = php, dO = pdo;
         if (t > 0) prefetch(t - 1);
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int row = 4 * q + reg;
-            float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f;
-            dhz[reg] = 0.f;
-            if (b0 + row < B) {
-                const float r = cr[reg], z = cz[reg], n = cn[reg], hn = chn[reg];
-                const float hp = chp[reg];
-                const float dh = cdo[reg] + dcarry[reg];
-                dn = dh * (1.f - z) * (1.f - n * n);
-                dz = dh * (hp - n) * z * (1.f - z);
-                dr = dn * hn * r * (1.f - r);
-                dnr = dn * r;
-                dhz[reg] = dh * z;
-                const size_t g = ((size_t)t * B + b0 + row) * 3 * GRU_H, gq = gru_gi_row(b0 + row, t, T, B, gi_agents) * 3 * GRU_H;
-                dgi[gq + j] = dr; dgi[gq + GRU_H + j] = dz; dgi[gq + 2 * GRU_H + j] = dn;
-                dgh[g + j] = dr; dgh[g + GRU_H + j] = dz; dgh[g + 2 * GRU_H + j] = dnr;
-                sb_r += dr; sb_z += dz; sb_n += dn; sb_nr += dnr;
-            }
-            gs[gru_gidx(row, j)] = dr; gs[gru_gidx(row, GRU_H + j)] = dz; gs[gru_gidx(row, 2 * GRU_H + j)] = dnr;
+        float4 dr, dz, dn, dnr, dhz;
+#define GRU2_ONE(f)                                              \
+        {                                                        \
+            const float dh = dO.f + dcarry.f;                    \
+            dn.f = dh * (1.f - z.f) * (1.f - n.f * n.f);         \
+            dz.f = dh * (hp.f - n.f) * z.f * (1.f - z.f);        \
+            dr.f = dn.f * hn.f * r.f * (1.f - r.f);              \
+            dnr.f = dn.f * r.f;                                  \
+            dhz.f = dh * z.f;                                    \
         }
-        __syncthreads();
-        const float *gp = &gs[(q * GRU_RB + c16) * GRU_LD3];
+        GRU2_ONE(x) GRU2_ONE(y) GRU2_ONE(z) GRU2_ONE(w)
+#undef GRU2_ONE
+        if (live) {
+            float *g = dgi + gru_gi_row(b0 + row, t, T, B, gi_agents) * 3 * GRU_H + u0;
+            *(float4 *)g = dr; *(float4 *)(g + GRU_H) = dz; *(float4 *)(g + 2 * GRU_H) = dn;
+            const size_t tb = (size_t)t * B + b0 + row;
+            if (dgh) {
+                float *h = dgh + tb * 3 * GRU_H + u0;
+                *(float4 *)h = dr; *(float4 *)(h + GRU_H) = dz; *(float4 *)(h + 2 * GRU_H) = dnr;
+            } else {
+                *(float4 *)(dnr_out + tb * GRU_H + u0) = dnr;
+            }
+#define GRU2_ACC(S, V) S.x += V.x; S.y += V.y; S.z += V.z; S.w += V.w;
+            GRU2_ACC(sb_r, dr) GRU2_ACC(sb_z, dz) GRU2_ACC(sb_n, dn) GRU2_ACC(sb_nr, dnr)
+#undef GRU2_ACC
+        }
+        float *gb = gs[buf];   // dead rows carry zeros (their loads were skipped)
+        *(float4 *)(gb + gpos[0]) = dr; *(float4 *)(gb + gpos[1]) = dz; *(float4 *)(gb + gpos[2]) = dnr;
+        lds_barrier();
+        const float *gp = gb + (q * GRU_RB + c16) * GRU2_LD3;   // B operand: dgh[row c16][96 q + s]
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
         for (int k4 = 0; k4 < 24; k4 += 3) {
             const f32x4 x0 = *(const f32x4 *)(gp + 4 * k4), x1 = *(const f32x4 *)(gp + 4 * k4 + 4), x2 = *(const f32x4 *)(gp + 4 * k4 + 8);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[u], wb[4 * k4 + u], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[u], wb[4 * k4 + 4 + u], a1, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[u], wb[4 * k4 + 8 + u], a2, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[4 * k4 + u], x0[u], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[4 * k4 + 4 + u], x1[u], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[4 * k4 + 8 + u], x2[u], a2, 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) dcarry[reg] = dhz[reg] + (a0[reg] + a1[reg] + a2[reg]);
-        __syncthreads();
+        dcarry.x = dhz.x + (a0[0] + a1[0] + a2[0]); dcarry.y = dhz.y + (a0[1] + a1[1] + a2[1]);
+        dcarry.z = dhz.z + (a0[2] + a1[2] + a2[2]); dcarry.w = dhz.w + (a0[3] + a1[3] + a2[3]);
+        buf ^= 1;   // the other tile: its last readers passed this step's barrier before anyone writes it again
     }
+    if (live) *(float4 *)(dh0 + (size_t)(b0 + row) * GRU_H + u0) = dcarry;
+    // bias gradients: sums over this workgroup's 16 rows (the lanes of a 16-lane group) and all steps
+    if (bias_partials) {
+        float s[16] = {sb_r.x, sb_r.y, sb_r.z, sb_r.w, sb_z.x, sb_z.y, sb_z.z, sb_z.w, sb_n.x, sb_n.y, sb_n.z, sb_n.w, sb_nr.x, sb_nr.y, sb_nr.z, sb_nr.w};
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) {
-        const int row = 4 * q + reg;
-        if (b0 + row < B) dh0[(size_t)(b0 + row) * GRU_H + j] = dcarry[reg];
-    }
-    // bias gradients: db_ih = sum (dr, dz, dn), db_hh = sum (dr, dz, dn r): per-workgroup partials, reduced by a second pass
-    sb_r += __shfl_xor(sb_r, 16); sb_z += __shfl_xor(sb_z, 16); sb_n += __shfl_xor(sb_n, 16); sb_nr += __shfl_xor(sb_nr, 16);
-    sb_r += __shfl_xor(sb_r, 32); sb_z += __shfl_xor(sb_z, 32); sb_n += __shfl_xor(sb_n, 32); sb_nr += __shfl_xor(sb_nr, 32);
-    if (q == 0 && bias_partials) {
-        float *bp = bias_partials + (size_t)blockIdx.x * 4 * GRU_H;
-        bp[j] = sb_r; bp[GRU_H + j] = sb_z; bp[2 * GRU_H + j] = sb_n; bp[3 * GRU_H + j] = sb_nr;
+        for (int i = 0; i < 16; i++) {
+            s[i] += __shfl_xor(s[i], 1); s[i] += __shfl_xor(s[i], 2); s[i] += __shfl_xor(s[i], 4); s[i] += __shfl_xor(s[i], 8);
+        }
+        if (c16 == 0) {
+            float *bp = bias_partials + (size_t)blockIdx.x * 4 * GRU_H + u0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) *(float4 *)(bp + g * GRU_H) = make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+        }
     }
 }
 
@@ -2057,23 +2096,31 @@ int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, cons
     return (int)hipGetLastError();
 }
 
+int64_t gru_seq_save_elems(int32_t T, int32_t B) { return (int64_t)T * ((B + GRU_RB - 1) / GRU_RB) * 4 * 512 * 4; }
+
 int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
                 float *save, int32_t gi_agents, void *stream) {
     if (T < 1 || B < 1 || H != GRU_H || !gi || !w_hh || !b_hh || !h0 || !out || gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k_gru_seq_fwd, dim3((B + GRU_RB - 1) / GRU_RB), dim3(512), 0, (hipStream_t)stream, T, B, gi, w_hh, b_hh, h0, out, save, (int)gi_agents);
+    if ((((uintptr_t)gi | (uintptr_t)w_hh | (uintptr_t)b_hh | (uintptr_t)h0 | (uintptr_t)out | (uintptr_t)save) & 15)) return MO_ERR_BAD_ARG;
+    const int nblk = (B + GRU_RB - 1) / GRU_RB;
+    hipLaunchKernelGGL(k_gru_seq_fwd2, dim3(nblk), dim3(512), 0, (hipStream_t)stream, T, B, gi, w_hh, b_hh, h0, out, save, (int)gi_agents);
     return (int)hipGetLastError();
 }
 
 int64_t gru_seq_bwd_workspace(int32_t B) { return (int64_t)((B + GRU_RB - 1) / GRU_RB) * 4 * GRU_H * sizeof(float); }
 
 int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0, const float *w_hh,
-                float *dgi, float *dgh, float *dh0, float *db_ih, float *db_hh, int32_t gi_agents, void *workspace, void *stream) {
-    if (T < 1 || B < 1 || H != GRU_H || !dout || !save || !out || !h0 || !w_hh || !dgi || !dgh || !dh0) return MO_ERR_BAD_ARG;
+                float *dgi, float *dgh, float *dnr, float *dh0, float *db_ih, float *db_hh, int32_t gi_agents, void *workspace, void *stream) {
+    if (T < 1 || B < 1 || H != GRU_H || !dout || !save || !out || !h0 || !w_hh || !dgi || !dh0) return MO_ERR_BAD_ARG;
+    if ((dgh == nullptr) == (dnr == nullptr)) return MO_ERR_BAD_ARG;        // exactly one of the two forms
     if (gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
     if ((db_ih || db_hh) && (!db_ih || !db_hh || !workspace)) return MO_ERR_BAD_ARG;
+    if ((((uintptr_t)dout | (uintptr_t)save | (uintptr_t)out | (uintptr_t)h0 | (uintptr_t)dgi | (uintptr_t)dgh | (uintptr_t)dnr | (uintptr_t)dh0 |
+          (uintptr_t)workspace) & 15)) return MO_ERR_BAD_ARG;
     const int nblk = (B + GRU_RB - 1) / GRU_RB;
-    hipLaunchKernelGGL(k_gru_seq_bwd, dim3(nblk), dim3(512), 0, (hipStream_t)stream, T, B, dout, save, out, h0, w_hh, dgi, dgh, dh0,
-                       db_ih ? (float *)workspace : (float *)nullptr, (int)gi_agents);
+    float *bp = db_ih ? (float *)workspace : (float *)nullptr;
+    hipLaunchKernelGGL(k_gru_seq_bwd2, dim3(nblk), dim3(512), 0, (hipStream_t)stream, T, B, dout, save, out, h0, w_hh, dgi, dgh, dnr, dh0, bp,
+                       (int)gi_agents);
     if (db_ih)
         hipLaunchKernelGGL(k_gru_bias_reduce, dim3(4 * GRU_H / 4), dim3(256), 0, (hipStream_t)stream, nblk, (const float *)workspace, db_ih, db_hh);
     return (int)hipGetLastError();

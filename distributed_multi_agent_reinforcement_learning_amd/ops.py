@@ -15,7 +15,7 @@ ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -56,7 +56,9 @@ def load_library():
         L.gru_gates_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_cell_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
-        L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+        L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+        L.gru_seq_save_elems.argtypes = [i32, i32]
+        L.gru_seq_save_elems.restype = i64
         L.gru_seq_bwd_workspace.argtypes = [i32]
         L.gru_seq_bwd_workspace.restype = i64
         L.wgrad_tn_workspace.argtypes = [i32, i32]
@@ -777,7 +779,11 @@ class _GRULayer(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
         gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())
-        save = torch.empty((T, 4, B, H), dtype=x.dtype, device=x.device) if need else None
+        # the saved gates: (T, 4, B, H) planes for the per-step path; the persistent pair keeps them in its own lane order
+        save = None
+        if need:
+            save = (torch.empty(L.gru_seq_save_elems(T, B), dtype=x.dtype, device=x.device) if persistent
+                    else torch.empty((T, 4, B, H), dtype=x.dtype, device=x.device))
         b_hh = b_hh.contiguous()
         st = _stream()
         ctx.persistent, ctx.dims, ctx.agents = persistent, (T, B, I), int(agents)
@@ -809,16 +815,20 @@ class _GRULayer(torch.autograd.Function):
         H = w_hh.shape[1]
         dout = dout.contiguous()
         dgi = torch.empty((T * B, 3 * H), dtype=x.dtype, device=x.device)   # rows in x's order
-        dgh = torch.empty((T, B, 3 * H), dtype=x.dtype, device=x.device)
         dh_direct = torch.empty((B, H), dtype=x.dtype, device=x.device)
         dcarry = None
         st = _stream()
         db_ih = db_hh = None
+        # dW_hh = [dr dz dnr]^T h_prev.  Time-major dgi rows line up with h_prev = out[t - 1], so dr, dz are stored once (dgi)
+        # and only dnr separately; with the encoder's row order (agents) the kernel writes the full time-major dgh as well.
+        split = bool(ctx.persistent and not ctx.agents)
+        dgh = None if split else torch.empty((T, B, 3 * H), dtype=x.dtype, device=x.device)
+        dnr = torch.empty((T, B, H), dtype=x.dtype, device=x.device) if split else None
         if ctx.persistent:
             db_ih = torch.empty(3 * H, dtype=x.dtype, device=x.device)
             db_hh = torch.empty(3 * H, dtype=x.dtype, device=x.device)
             ws = torch.empty(L.gru_seq_bwd_workspace(B), dtype=torch.uint8, device=x.device)
-            _check(L.gru_seq_bwd(T, B, H, _ptr(dout), _ptr(save), _ptr(out), _ptr(h0), _ptr(w_hh), _ptr(dgi), _ptr(dgh), _ptr(dh_direct),
+            _check(L.gru_seq_bwd(T, B, H, _ptr(dout), _ptr(save), _ptr(out), _ptr(h0), _ptr(w_hh), _ptr(dgi), _ptr(dgh), _ptr(dnr), _ptr(dh_direct),
                                  _ptr(db_ih), _ptr(db_hh), ctx.agents, _ptr(ws), st), "gru_seq_bwd")
             dcarry = dh_direct
         else:
@@ -828,10 +838,18 @@ class _GRULayer(torch.autograd.Function):
                 _check(L.gru_gates_bwd(B, H, _ptr(dout[t]), _ptr(dcarry), _ptr(save[t]), _ptr(hprev), _ptr(dgi3[t]), _ptr(dgh[t]),
                                        _ptr(dh_direct), st), "gru_gates_bwd")
                 dcarry = torch.addmm(dh_direct, dgh[t], w_hh)
-        dgh2 = dgh.reshape(T * B, 3 * H)
-        dw_hh = torch.mm(dgh[0].t(), h0)
-        if T > 1:
-            wgrad(dgh[1:].reshape((T - 1) * B, 3 * H), out[:-1].reshape((T - 1) * B, H), out=dw_hh, accumulate=True)
+        if split:
+            dw_hh = torch.empty((3 * H, H), dtype=x.dtype, device=x.device)
+            drz, hp = dgi[:, :2 * H], out[:-1].reshape((T - 1) * B, H)     # (dr, dz): a column slice of dgi, rows strided, no copy
+            torch.mm(drz[:B].t(), h0, out=dw_hh[:2 * H])
+            torch.mm(dnr[0].t(), h0, out=dw_hh[2 * H:])
+            if T > 1:
+                wgrad(drz[B:], hp, out=dw_hh[:2 * H], accumulate=True)
+                wgrad(dnr[1:].reshape((T - 1) * B, H), hp, out=dw_hh[2 * H:], accumulate=True)
+        else:
+            dw_hh = torch.mm(dgh[0].t(), h0)
+            if T > 1:
+                wgrad(dgh[1:].reshape((T - 1) * B, 3 * H), out[:-1].reshape((T - 1) * B, H), out=dw_hh, accumulate=True)
         x2 = x.reshape(T * B, I)
         dw_ih = wgrad(dgi, x2)
         dx = None
@@ -842,7 +860,7 @@ class _GRULayer(torch.autograd.Function):
                 dx = dx.reshape(T, B // P, P, I).permute(1, 0, 2, 3)
             dx = dx.reshape(ctx.x_shape)
         if db_ih is None:
-            db_ih, db_hh = dgi.sum(0), dgh2.sum(0)
+            db_ih, db_hh = dgi.sum(0), dgh.reshape(T * B, 3 * H).sum(0)
         return dx, dcarry, dw_ih, dw_hh, db_ih, db_hh, None, None, None
 
 

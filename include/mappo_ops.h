@@ -166,22 +166,28 @@ int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, 
 /*
  * Whole-sequence GRU layer in one persistent launch (H = 128 only): gi [T B][3H] is the input projection
  * x W_ih^T + b_ih (one MFMA GEMM), the recurrence over T runs inside the kernel with W_hh held in registers as
- * v_mfma_f32_16x16x4_f32 operands and the h tile (16 batch rows per workgroup) in LDS.  out [T][B][H];
- * save [T][4][B][H] (r, z, n, hn) or NULL.  The backward kernel consumes dout [T][B][H] (dL/d out) and produces
- * dgi [T B][3H], dgh [T][B][3H] (inputs of the weight-gradient GEMMs) and dh0 [B][H].
+ * v_mfma_f32_16x16x4_f32 operands and the h tile (16 batch rows per workgroup) in LDS.  out [T][B][H] time-major.
+ * save (or NULL: no backward): gru_seq_save_elems(T, B) floats, the gates (r, z, n, hn) of every step in the kernel pair's own
+ * lane order -- opaque, only gru_seq_bwd reads it.  The backward kernel consumes dout [T][B][H] (dL/d out) and produces
+ * dgi [T B][3H] = (dr, dz, dn), dh0 [B][H] and, for the recurrent weight gradient dW_hh = [dr dz dnr]^T h_prev, EITHER
+ * dgh [T][B][3H] = (dr, dz, dnr) time-major OR only dnr [T][B][H] (exactly one of the two pointers is non-NULL).  The second
+ * form stores dr, dz once: valid when dgi itself is time-major (gi_agents == 0), the caller then takes the first 2H columns of
+ * dgh from dgi.
  * gi_agents: row order of gi and dgi.  0: time-major, row t B + b.  P > 0: the order of the encoder's output rows
  * (episode n, step t, agent p) with sequence b = n P + p, row ((b / P) T + t) P + b % P (B a multiple of P) -- the input
  * projection and its gradients then run on the embedding as it lies in memory, without the permuted copies around the GRU
  * (_sequence_features, DHGN/mappo_parallel.py:426-437).
+ * All pointers 16-byte aligned.
  */
+int64_t gru_seq_save_elems(int32_t T, int32_t B);
 int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
                 float *save, int32_t gi_agents, void *stream);
 int64_t gru_seq_bwd_workspace(int32_t B);
 /* db_ih / db_hh [3H] (optional, both or none): column sums of dgi / dgh, reduced from per-workgroup partials in
  * `workspace` (>= gru_seq_bwd_workspace(B) bytes) by a deterministic second pass. */
 int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0,
-                const float *w_hh, float *dgi, float *dgh, float *dh0, float *db_ih, float *db_hh, int32_t gi_agents, void *workspace,
-                void *stream);
+                const float *w_hh, float *dgi, float *dgh, float *dnr, float *dh0, float *db_ih, float *db_hh, int32_t gi_agents,
+                void *workspace, void *stream);
 
 /*
  * One torch.nn.GRU layer step for a large batch without autograd (the rollout's choose_action / get_value,

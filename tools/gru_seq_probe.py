@@ -9,8 +9,8 @@ dev = "cuda"
 ptr = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 gi = torch.randn(T, B, 3 * H, device=dev); w = torch.randn(3 * H, H, device=dev) * 0.08; b = torch.zeros(3 * H, device=dev)
-h0 = torch.zeros(B, H, device=dev); out = torch.empty(T, B, H, device=dev); save = torch.empty(T, 4, B, H, device=dev)
-dout = torch.randn(T, B, H, device=dev); dgi = torch.empty(T, B, 3 * H, device=dev); dgh = torch.empty_like(dgi); dh0 = torch.empty(B, H, device=dev)
+h0 = torch.zeros(B, H, device=dev); out = torch.empty(T, B, H, device=dev); save = torch.empty(L.gru_seq_save_elems(T, B), device=dev)
+dout = torch.randn(T, B, H, device=dev); dgi = torch.empty(T, B, 3 * H, device=dev); dgh = torch.empty_like(dgi); dnr = torch.empty(T, B, H, device=dev); dh0 = torch.empty(B, H, device=dev)
 dbi = torch.empty(3 * H, device=dev); dbh = torch.empty(3 * H, device=dev)
 ws = torch.empty(L.gru_seq_bwd_workspace(B), dtype=torch.uint8, device=dev)
 def timeit(fn, n=10):
@@ -22,6 +22,7 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 tf = timeit(lambda: L.gru_seq_fwd(T, B, H, ptr(gi), ptr(w), ptr(b), ptr(h0), ptr(out), ptr(save), 0, st))
-tb = timeit(lambda: L.gru_seq_bwd(T, B, H, ptr(dout), ptr(save), ptr(out), ptr(h0), ptr(w), ptr(dgi), ptr(dgh), ptr(dh0), ptr(dbi), ptr(dbh), 0, ptr(ws), st))
+tb = timeit(lambda: L.gru_seq_bwd(T, B, H, ptr(dout), ptr(save), ptr(out), ptr(h0), ptr(w), ptr(dgi), ptr(dgh), None, ptr(dh0), ptr(dbi), ptr(dbh), 0, ptr(ws), st))
+tb2 = timeit(lambda: L.gru_seq_bwd(T, B, H, ptr(dout), ptr(save), ptr(out), ptr(h0), ptr(w), ptr(dgi), None, ptr(dnr), ptr(dh0), ptr(dbi), ptr(dbh), 0, ptr(ws), st))
 fl = 2.0 * T * B * H * 3 * H
-print(f"gru_seq_fwd {tf:.1f} us ({fl/tf/1e6:.1f} TFLOP/s, {tf/T:.2f} us/step)   gru_seq_bwd {tb:.1f} us ({fl/tb/1e6:.1f} TFLOP/s, {tb/T:.2f} us/step)")
+print(f"gru_seq_fwd {tf:.1f} us ({fl/tf/1e6:.1f} TFLOP/s, {tf/T:.2f} us/step)   gru_seq_bwd {tb:.1f} us ({fl/tb/1e6:.1f} TFLOP/s, {tb/T:.2f} us/step)  with dnr only {tb2:.1f} us")
