@@ -14,6 +14,8 @@ LIBS = {
     "libmappo_ops.so": (["mappo_ops.hip"], []),
     "libn2n_env.so": (["n2n_env.hip"], ["-ffp-contract=off", "-pthread"]),
     "libe3d_env.so": (["e3d_env.hip"], ["-ffp-contract=off", "-pthread"]),
+    # host-only: the strided-output GEMM + epilogue on hipBLASLt (include/mappo_gemm.h)
+    "libmappo_gemm.so": (["mappo_gemm.cpp"], ["-lhipblaslt"]),
 }
 
 

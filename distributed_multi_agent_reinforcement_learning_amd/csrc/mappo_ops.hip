@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDi
                             const void *__restrict__ adj2, const int32_t *__restrict__ kvalid2, const float *__restrict__ W2,
                             const float *__restrict__ b2, float *__restrict__ out, float *__restrict__ out_c, int c_valid,
                             const float *__restrict__ Wp, int64_t wp_rs, const float *__restrict__ bp, float *__restrict__ pos_a,
-                            float *__restrict__ pos_c) {
+                            float *__restrict__ pos_c, int64_t pos_ld) {
     const int E = d0.E;
     msgw_fwd_rows<PT, S01, S01, EV>(d0, p, q0, e0, adj0, kvalid2, W0, b0, out, out_c, false);
     msgw_fwd_rows<PT, S01, S01, EV>(d1, p, q1, e0, adj1, kvalid2, W1, b1, out + E, out_c ? out_c + E : nullptr, false);
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(256) void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDi
                 if (i < P) {
                     const FV<EV> v = fv_fma(wp[3], rl_f(vp, 4 * i + 3), fv_fma(wp[2], rl_f(vp, 4 * i + 2), fv_fma(wp[1], rl_f(vp, 4 * i + 1),
                                             fv_fma(wp[0], rl_f(vp, 4 * i), bias))));
-                    fv_store<EV>(pos_a + ((size_t)r * P + i) * E, f, fs, v);
-                    if (pos_c != nullptr) fv_store<EV>(pos_c + ((size_t)r * P + i) * E, f, fs, v);
+                    fv_store<EV>(pos_a + ((size_t)r * P + i) * pos_ld, f, fs, v);
+                    if (pos_c != nullptr) fv_store<EV>(pos_c + ((size_t)r * P + i) * pos_ld, f, fs, v);
                 }
         }
     }
@@ -1647,6 +1647,7 @@ struct NbrArgs {
     int R, P, E, T, relu;              // row r = (n, t) = (r / T, r % T)
     int64_t za_es, za_ts, zc_es, zc_ts;  // element strides of an episode / a step in za, zc
     int64_t adj_rs;                     // elements between adjacency rows
+    int64_t out_ld;                     // elements between the output vectors of consecutive agents (E: dense)
 };
 template <int PT>
 __global__ void k_nbr_mean(NbrArgs a, const float *__restrict__ za, const float *__restrict__ zc, const float *__restrict__ adj,
@@ -1688,7 +1689,7 @@ __global__ void k_nbr_mean(NbrArgs a, const float *__restrict__ za, const float 
                             if (j < P) acc = __builtin_fmaf(ar[j] / nrm, z[j], acc);
                     }
                     acc += bf;
-                    out_a[((size_t)r * P + i) * E + f] = a.relu ? fmaxf(acc, 0.f) : acc;
+                    out_a[((size_t)r * P + i) * a.out_ld + f] = a.relu ? fmaxf(acc, 0.f) : acc;
                 }
         }
         if (out_c) {
@@ -1699,7 +1700,7 @@ __global__ void k_nbr_mean(NbrArgs a, const float *__restrict__ za, const float 
                 if (j < P) acc = __builtin_fmaf(inv_p, zr[(size_t)j * E + f], acc);
             acc += bf;
             acc = a.relu ? fmaxf(acc, 0.f) : acc;
-            for (int i = 0; i < P; i++) out_c[((size_t)r * P + i) * E + f] = acc;
+            for (int i = 0; i < P; i++) out_c[((size_t)r * P + i) * a.out_ld + f] = acc;
         }
     }
 }
@@ -1709,8 +1710,9 @@ __global__ void k_nbr_mean(NbrArgs a, const float *__restrict__ za, const float 
 // Linear in front of the ReLU): autograd reads gin a second time for the sum (756 MB per mini-batch at DHGN's AGG layer);
 // here it is added up while it is written.  F a multiple of 4, <= 1024; rows of F contiguous floats.
 constexpr int RB_BLOCKS = 2048, RB_TPB = 256;
-__global__ __launch_bounds__(RB_TPB) void k_relu_bwd_colsum(int64_t R, int F, const float *__restrict__ gout, const float *__restrict__ y,
-                                                            float *__restrict__ gin, float *__restrict__ part) {
+__global__ __launch_bounds__(RB_TPB) void k_relu_bwd_colsum(int64_t R, int F, const float *__restrict__ gout, int64_t ldg4,
+                                                            const float *__restrict__ y, int64_t ldy4, float *__restrict__ gin,
+                                                            float *__restrict__ part) {   // ldg4, ldy4: row strides of gout / y in float4
     __shared__ float4 s_sum[RB_TPB];
     const int f4 = F >> 2;                 // float4 columns per row
     const int cpb = RB_TPB / f4;           // rows a workgroup covers per step (host: f4 divides RB_TPB)
@@ -1723,7 +1725,7 @@ __global__ __launch_bounds__(RB_TPB) void k_relu_bwd_colsum(int64_t R, int F, co
     for (; r + 3 * cpb < r1; r += 4 * cpb) {  // four rows in flight per lane
         float4 g[4], v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { g[u] = g4[(r + u * cpb) * f4 + col]; v[u] = y4[(r + u * cpb) * f4 + col]; }
+        for (int u = 0; u < 4; u++) { g[u] = g4[(r + u * cpb) * ldg4 + col]; v[u] = y4[(r + u * cpb) * ldy4 + col]; }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             float4 o;
@@ -1733,7 +1735,7 @@ __global__ __launch_bounds__(RB_TPB) void k_relu_bwd_colsum(int64_t R, int F, co
         }
     }
     for (; r < r1; r += cpb) {
-        const float4 g = g4[r * f4 + col], v = y4[r * f4 + col];
+        const float4 g = g4[r * ldg4 + col], v = y4[r * ldy4 + col];
         float4 o;
         o.x = v.x > 0.f ? g.x : 0.f; o.y = v.y > 0.f ? g.y : 0.f; o.z = v.z > 0.f ? g.z : 0.f; o.w = v.w > 0.f ? g.w : 0.f;
         o4[r * f4 + col] = o;
@@ -1842,7 +1844,7 @@ int wgrad_split(int M, int N, int *am, int *bn) {  // tile shape and number of K
 
 int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int64_t p_rs, const int32_t *kvalid2, float *out, float *out_c,
                  int c_valid, int64_t out_stride, void *stream, bool pair, const float *Wp = nullptr, int64_t wp_rs = 0, const float *bp = nullptr,
-                 float *pos_a = nullptr, float *pos_c = nullptr) {
+                 float *pos_a = nullptr, float *pos_c = nullptr, int64_t pos_ld = 0) {
     MsgDims d[3];
     int grid = 1;
     for (int r = 0; r < 3; r++) {
@@ -1859,7 +1861,7 @@ int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int
 #define MSGW3_LAUNCH1(PT, S01, AS2, EV)                                                                                                     \
     hipLaunchKernelGGL((k_msgw3_fwd<PT, S01, AS2, EV>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d[0], d[1], d[2], p, rel[0].q,       \
                        rel[0].e, rel[0].adj, rel[0].W, rel[0].b, rel[1].q, rel[1].adj, rel[1].W, rel[1].b, rel[2].q, rel[2].adj, kvalid2,      \
-                       rel[2].W, rel[2].b, out, out_c, c_valid, Wp, wp_rs, bp, pos_a, pos_c)
+                       rel[2].W, rel[2].b, out, out_c, c_valid, Wp, wp_rs, bp, pos_a, pos_c, pos_ld ? pos_ld : (int64_t)E)
 #define MSGW3_LAUNCH(PT, S01, AS2) do { if (ev2) MSGW3_LAUNCH1(PT, S01, AS2, 2); else MSGW3_LAUNCH1(PT, S01, AS2, 1); } while (0)
 #define MSGW3_PT(PT) { if (s01 && as2) MSGW3_LAUNCH(PT, true, true); else if (s01) MSGW3_LAUNCH(PT, true, false); else if (as2) MSGW3_LAUNCH(PT, false, true); else MSGW3_LAUNCH(PT, false, false); }
     if (P <= 8) MSGW3_PT(8) else MSGW3_PT(16)
@@ -1911,13 +1913,13 @@ int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t 
 
 int dhgn_msg_agg3_pair_pos_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_rs, const int32_t *o_kvalid,
                                float *out_actor, float *out_critic, int64_t out_stride, const float *Wp, int64_t wp_row_stride, const float *bp,
-                               float *pos_actor, float *pos_critic, void *stream) {
-    if (!rel || !p || !out_actor || !out_critic || R < 0 || !Wp || !bp || !pos_actor || wp_row_stride < 4) return MO_ERR_BAD_ARG;
+                               float *pos_actor, float *pos_critic, int64_t pos_stride, void *stream) {
+    if (!rel || !p || !out_actor || !out_critic || R < 0 || !Wp || !bp || !pos_actor || wp_row_stride < 4 || pos_stride < E) return MO_ERR_BAD_ARG;
     if (R == 0) return 0;
     for (int r = 0; r < 3; r++)
         if (rel[r].adj_mode != MO_ADJ_TENSOR && rel[r].adj_mode != MO_ADJ_BITS) return MO_ERR_BAD_ARG;
     return launch_msgw3(rel, R, P, E, p, p_rs, o_kvalid, out_actor, out_critic, o_kvalid != nullptr, out_stride, stream, true, Wp, wp_row_stride, bp,
-                        pos_actor, pos_critic);
+                        pos_actor, pos_critic, pos_stride);
 }
 
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD_BLOCKS * (din + 1) * E * sizeof(float); }
@@ -2150,11 +2152,11 @@ int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const
 
 int fcra_neighbour_mean(int32_t R, int32_t P, int32_t E, int32_t T, const float *z_actor, int64_t za_episode_stride, int64_t za_step_stride,
                         const float *z_critic, int64_t zc_episode_stride, int64_t zc_step_stride, const float *adj, int64_t adj_row_stride,
-                        const float *bias, int32_t relu, float *out_actor, float *out_critic, void *stream) {
-    if (R < 0 || P < 1 || P > MAX_P || E < 64 || E > 1024 || (E & 63) || T < 1 || (R % T)) return MO_ERR_BAD_ARG;
+                        const float *bias, int32_t relu, float *out_actor, float *out_critic, int64_t out_stride, void *stream) {
+    if (R < 0 || P < 1 || P > MAX_P || E < 64 || E > 1024 || (E & 63) || T < 1 || (R % T) || out_stride < E) return MO_ERR_BAD_ARG;
     if ((out_actor && (!z_actor || !adj)) || (out_critic && !z_critic) || (!out_actor && !out_critic)) return MO_ERR_BAD_ARG;
     if (R == 0) return 0;
-    NbrArgs a{R, P, E, T, relu, za_episode_stride, za_step_stride, zc_episode_stride, zc_step_stride, adj_row_stride};
+    NbrArgs a{R, P, E, T, relu, za_episode_stride, za_step_stride, zc_episode_stride, zc_step_stride, adj_row_stride, out_stride};
     const int grid = R < 16384 ? R : 16384;
     if (P <= 8) hipLaunchKernelGGL(k_nbr_mean<8>, dim3(grid), dim3(E), 0, (hipStream_t)stream, a, z_actor, z_critic, adj, bias, out_actor, out_critic);
     else hipLaunchKernelGGL(k_nbr_mean<16>, dim3(grid), dim3(E), 0, (hipStream_t)stream, a, z_actor, z_critic, adj, bias, out_actor, out_critic);
@@ -2163,14 +2165,16 @@ int fcra_neighbour_mean(int32_t R, int32_t P, int32_t E, int32_t T, const float 
 
 int64_t relu_bwd_colsum_workspace(int32_t F) { return (int64_t)RB_BLOCKS * F * sizeof(float); }
 
-int relu_bwd_colsum(int64_t R, int32_t F, const float *gout, const float *y, float *gin, float *colsum, void *workspace, void *stream) {
+int relu_bwd_colsum(int64_t R, int32_t F, const float *gout, int64_t g_row_stride, const float *y, int64_t y_row_stride, float *gin, float *colsum,
+                    void *workspace, void *stream) {
     if (R < 1 || F < 4 || (F & 3) || F > 1024 || (RB_TPB % (F >> 2)) || !gout || !y || !gin || !colsum || !workspace) return MO_ERR_BAD_ARG;
+    if (g_row_stride < F || y_row_stride < F || (g_row_stride & 3) || (y_row_stride & 3)) return MO_ERR_BAD_ARG;
     if ((((uintptr_t)gout | (uintptr_t)y | (uintptr_t)gin) & 15)) return MO_ERR_BAD_ARG;
     const int64_t rows_per_step = RB_TPB / (F >> 2);
     int64_t want = (R + rows_per_step - 1) / rows_per_step;
     const int grid = want < RB_BLOCKS ? (int)want : RB_BLOCKS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_relu_bwd_colsum, dim3(grid), dim3(RB_TPB), 0, st, R, (int)F, gout, y, gin, (float *)workspace);
+    hipLaunchKernelGGL(k_relu_bwd_colsum, dim3(grid), dim3(RB_TPB), 0, st, R, (int)F, gout, g_row_stride >> 2, y, y_row_stride >> 2, gin, (float *)workspace);
     hipLaunchKernelGGL(k_colsum_reduce, dim3((F + 3) / 4), dim3(256), 0, st, grid, (int)F, (const float *)workspace, colsum);
     return (int)hipGetLastError();
 }

@@ -95,20 +95,17 @@ class DHGN(nn.Module):
     # -- fixed-depth recursive aggregation over neighbours' historical embeddings (:204-233) --------------
     def fcra(self, h0, hist, adj_p, is_critic, out=None):
         """hist: sequence of `depth` tensors (R,P,E), hop k = hist[k] (k = 0 is the most recent)."""
-        h = h0
-        E = self.embedding_dim
         if self.depth == 0:
-            return h
+            return h0
+        h, cat = h0, None
         for k in range(self.depth):
-            aggk = self.AGG_layers[f"AGG_fcra_{k}"]
+            aggk, fk = self.AGG_layers[f"AGG_fcra_{k}"], self.FCRA_layers[k]
             # matmul(normalize(adj or ones, p=1), hist[k]): one pass, the history slice read in place (hist is stored data)
             nb = ops.fcra_mean(z_critic=hist[k]) if is_critic else ops.fcra_mean(z_actor=hist[k], adj=adj_p)
-            agg = ops.linear(nb, aggk.weight, aggk.bias, relu=True)
-            Wf = self.FCRA_layers[k].weight  # FCRA_k([agg, h]) as two accumulating GEMMs instead of a concatenation
-            last = out is not None and k == self.depth - 1
-            # the h-part lands in the static storage on the last hop (rollout, no autograd), the agg-part accumulates into it
-            t = ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias, out=out if last else None)
-            h = ops.linear(agg, Wf[:, :E], t, relu=True, consume_addend=True)
+            last = k == self.depth - 1
+            # FCRA_k([relu(AGG_k(nb)) | h]) as one K = 2E GEMM whose operand halves are written in place by their producers
+            # (ops.fcra_hop); the last hop of a rollout lands in the static storage
+            h, cat = ops.fcra_hop(nb, h, cat, aggk.weight, aggk.bias, fk.weight, fk.bias, last, out if last else None)
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):
@@ -127,7 +124,16 @@ class DHGN(nn.Module):
         E, ind = self.embedding_dim, self.input_dim
         M = self.MSG_layers
         Ws = self.semantic_layer.weight
-        h0 = out if (out is not None and self.depth == 0) else torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
+        d = self.depth
+        # [agg | h] operands of the FCRA layers, one per hop: each layer is ONE K = 2E GEMM (bias + ReLU in its epilogue) whose
+        # halves are written in place by their producers -- the neighbour-mean kernel (left) and the previous layer / the
+        # semantic layer (right) -- so neither a concatenation nor a separate ReLU pass exists
+        cats = [torch.empty((2, R, P, 2 * E), dtype=p.dtype, device=p.device) for _ in range(d)]
+        if d:
+            h0 = cats[0][..., E:]
+        else:
+            h0 = out if out is not None else torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
+        h0_2d = ops.block2d(h0)
         fused_pos = ind == 4
         # the message launch also leaves the semantic layer's position part (the same for both networks) in h0
         m3 = ops.msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
@@ -135,26 +141,29 @@ class DHGN(nn.Module):
         agg0 = self.AGG_layers["AGG_vertex_0"]
         emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)
         if not fused_pos:
-            o2 = h0.view(2, R * P, E)
-            torch.addmm(self.semantic_layer.bias, p.reshape(R * P, ind), Ws[:, :ind].t(), out=o2[0])
-            o2[1].copy_(o2[0])
-        h0.view(2 * R * P, E).addmm_(emb.view(2 * R * P, 3 * E), Ws[:, ind:].t())
-        if self.depth == 0:
+            torch.addmm(self.semantic_layer.bias, p.reshape(R * P, ind), Ws[:, :ind].t(), out=h0_2d[:R * P])
+            h0_2d[R * P:].copy_(h0_2d[:R * P])
+        if d:   # h0 is the right half of the first hop's operand: accumulate into it in place (beta = 1, strided output)
+            ops.gemm_nt(emb.view(2 * R * P, 3 * E), Ws[:, ind:], None, False, out=h0_2d, addend=h0_2d)
+        else:
+            h0_2d.addmm_(emb.view(2 * R * P, 3 * E), Ws[:, ind:].t())
+        if d == 0:
             return h0
         h = h0
-        for k in range(self.depth):
-            aggk = self.AGG_layers[f"AGG_fcra_{k}"]
+        for k in range(d):
+            aggk, fk = self.AGG_layers[f"AGG_fcra_{k}"], self.FCRA_layers[k]
             # relu((abar @ hist) W^T + b) evaluated as relu(abar @ (hist W^T) + b): in the reference's rollout both networks read
             # the same history list, so the GEMM runs once for the two of them; the two neighbour means, the bias
-            # and the ReLU are one launch
+            # and the ReLU are one launch that writes the left half of the hop's operand
             za = ops.linear(hist_a[k], aggk.weight)
             zc = za if hist_c[k] is hist_a[k] or hist_c[k].data_ptr() == hist_a[k].data_ptr() else ops.linear(hist_c[k], aggk.weight)
-            agg = ops.fcra_mean(z_actor=za, z_critic=zc, adj=adj_p, bias=aggk.bias, relu=True)
-            Wf = self.FCRA_layers[k].weight
-            last = out is not None and k == self.depth - 1
-            # the h-part lands in the static storage on the last hop (rollout, no autograd), the agg-part accumulates into it
-            t = ops.linear(h, Wf[:, E:], self.FCRA_layers[k].bias, out=out if last else None)
-            h = ops.linear(agg, Wf[:, :E], t, relu=True, consume_addend=True)
+            ops.fcra_mean(z_actor=za, z_critic=zc, adj=adj_p, bias=aggk.bias, relu=True, out=cats[k][..., :E])
+            last = k == d - 1
+            if not last:
+                h = cats[k + 1][..., E:]
+            else:
+                h = out if out is not None else torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
+            ops.gemm_nt(cats[k].view(2 * R * P, 2 * E), fk.weight, fk.bias, True, out=ops.block2d(h))
         return h
 
 

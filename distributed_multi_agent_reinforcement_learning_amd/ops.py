@@ -38,7 +38,7 @@ def load_library():
         L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.dhgn_msg_agg3_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, i64, vp]
         L.dhgn_msg_agg3_pair_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp]
-        L.dhgn_msg_agg3_pair_pos_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp]
+        L.dhgn_msg_agg3_pair_pos_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
         L.spectral_norm_weight.argtypes = [i32, i32, vp, vp, vp, f32, i32, vp, vp]
         L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
         L.dhgn_msg_agg_bwd_workspace.restype = i64
@@ -64,10 +64,10 @@ def load_library():
         L.wgrad_tn_workspace.argtypes = [i32, i32]
         L.wgrad_tn_workspace.restype = i64
         L.wgrad_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
-        L.fcra_neighbour_mean.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, vp, vp, vp]
+        L.fcra_neighbour_mean.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, vp, vp, i64, vp]
         L.relu_bwd_colsum_workspace.argtypes = [i32]
         L.relu_bwd_colsum_workspace.restype = i64
-        L.relu_bwd_colsum.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
+        L.relu_bwd_colsum.argtypes = [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp]
         L.wgrad_skinny_workspace.argtypes = [i32, i32]
         L.wgrad_skinny_workspace.restype = i64
         L.wgrad_skinny.argtypes = [i64, i32, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp]
@@ -122,6 +122,19 @@ def unpack_adj_bits(bits, K):
     sh = torch.arange(32, device=bits.device, dtype=torch.int32)
     b = (bits.unsqueeze(-1) >> sh) & 1
     return b.reshape(*bits.shape[:-1], -1)[..., :K].to(torch.float32)
+
+
+def _vec_stride(t):
+    """t (..., E): the E-vectors of all leading positions, in C order, are `ld` elements apart (ld = E: a dense tensor; ld > E: a
+    column block of a dense (rows, ld) matrix).  Returns ld; asserts that layout."""
+    E = t.shape[-1]
+    ld = t.stride(-2) if t.dim() > 1 else E
+    assert t.stride(-1) == 1 and ld >= E
+    n = 1
+    for k in range(t.dim() - 2, -1, -1):
+        assert t.shape[k] == 1 or t.stride(k) == n * ld, "not a column block of a dense matrix"
+        n *= t.shape[k]
+    return ld
 
 
 def _rows_ok(t):
@@ -263,9 +276,10 @@ def msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, o_kvalid
         # layer's position part bp + Wp p for both networks into h0
         Wp, bp, h0 = pos
         Wp, bp = Wp.detach(), bp.detach().contiguous()
-        assert Wp.shape == (E, 4) and Wp.stride(1) == 1 and h0.shape == (2, R, P, E) and h0.is_contiguous()
+        ld = _vec_stride(h0)   # E (dense) or the row length of a wider matrix whose column block h0 is
+        assert Wp.shape == (E, 4) and Wp.stride(1) == 1 and h0.shape == (2, R, P, E)
         _check(L.dhgn_msg_agg3_pair_pos_fwd(C.cast(arr, C.c_void_p), R, P, E, _ptr(p), p.stride(0), _ptr(o_kvalid), _ptr(out[0]), _ptr(out[1]), 3 * E,
-                                            _ptr(Wp), Wp.stride(0), _ptr(bp), _ptr(h0[0]), _ptr(h0[1]), _stream()), "dhgn_msg_agg3_pair_pos_fwd")
+                                            _ptr(Wp), Wp.stride(0), _ptr(bp), _ptr(h0[0]), _ptr(h0[1]), ld, _stream()), "dhgn_msg_agg3_pair_pos_fwd")
         return out
     _check(L.dhgn_msg_agg3_pair_fwd(C.cast(arr, C.c_void_p), R, P, E, _ptr(p), p.stride(0), _ptr(o_kvalid), _ptr(out[0]), _ptr(out[1]), 3 * E,
                                     _stream()), "dhgn_msg_agg3_pair_fwd")
@@ -506,7 +520,8 @@ def fcra_mean(z_actor=None, z_critic=None, adj=None, bias=None, relu=False, out=
     both = z_actor is not None and z_critic is not None
     if out is None:
         out = torch.empty(((2, R, P, E) if both else (R, P, E)), dtype=torch.float32, device=z.device)
-    assert out.is_contiguous() and out.numel() == (2 if both else 1) * R * P * E
+    assert out.numel() == (2 if both else 1) * R * P * E and out.shape[-1] == E
+    out_ld = _vec_stride(out)   # dense, or the left half of an [agg | h] operand
     za = zc = None
     T = 1
     a_es = a_ts = c_es = c_ts = 0
@@ -521,7 +536,7 @@ def fcra_mean(z_actor=None, z_critic=None, adj=None, bias=None, relu=False, out=
     o_c = (out[1] if both else out) if z_critic is not None else None
     adj3 = adj.reshape(R, P, P) if adj is not None else None
     _check(L.fcra_neighbour_mean(R, P, E, T, _ptr(za), a_es, a_ts, _ptr(zc), c_es, c_ts, _ptr(adj3), adj3.stride(0) if adj3 is not None else 0,
-                                 _ptr(bias.detach() if bias is not None else None), int(bool(relu)), _ptr(o_a), _ptr(o_c), _stream()),
+                                 _ptr(bias.detach() if bias is not None else None), int(bool(relu)), _ptr(o_a), _ptr(o_c), out_ld, _stream()),
            "fcra_neighbour_mean")
     return out
 
@@ -531,18 +546,26 @@ RELU_BWD_MIN_ROWS = 4096
 
 def relu_bwd_colsum(g, y):
     """(g * (y > 0), its column sums): ReLU backward from the saved output and the bias gradient of the Linear in front of it
-    in one pass (csrc/mappo_ops.hip k_relu_bwd_colsum); small or odd shapes take the two torch ops."""
+    in one pass (csrc/mappo_ops.hip k_relu_bwd_colsum); small or odd shapes take the two torch ops.  g, y: dense, or column
+    blocks of wider matrices (last stride 1, one row stride); the result is dense."""
     F_ = g.shape[-1]
     rows = g.numel() // max(F_, 1)
-    if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and y.is_contiguous() and y.shape == g.shape and rows >= RELU_BWD_MIN_ROWS
-            and F_ % 4 == 0 and F_ <= 1024 and 256 % (F_ // 4) == 0 and g.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
+
+    def ld(t):
+        try:
+            return _vec_stride(t)
+        except AssertionError:
+            return None
+    lg, ly = ld(g), ld(y)
+    if not (g.is_cuda and g.dtype == torch.float32 and y.shape == g.shape and rows >= RELU_BWD_MIN_ROWS and lg is not None and ly is not None
+            and lg % 4 == 0 and ly % 4 == 0 and F_ % 4 == 0 and F_ <= 1024 and 256 % (F_ // 4) == 0 and g.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
         gin = torch.ops.aten.threshold_backward(g, y, 0.0)
         return gin, gin.reshape(-1, F_).sum(0)
     L = load_library()
-    gin = torch.empty_like(g)
+    gin = torch.empty(g.shape, dtype=g.dtype, device=g.device)
     cs = torch.empty(F_, dtype=g.dtype, device=g.device)
     ws = torch.empty(L.relu_bwd_colsum_workspace(F_), dtype=torch.uint8, device=g.device)
-    _check(L.relu_bwd_colsum(rows, F_, _ptr(g), _ptr(y), _ptr(gin), _ptr(cs), _ptr(ws), _stream()), "relu_bwd_colsum")
+    _check(L.relu_bwd_colsum(rows, F_, _ptr(g), lg, _ptr(y), ly, _ptr(gin), _ptr(cs), _ptr(ws), _stream()), "relu_bwd_colsum")
     return gin, cs
 
 
@@ -669,7 +692,7 @@ class _Linear(torch.autograd.Function):
         want_db = bool(ctx.bias_kind and ctx.needs_input_grad[2])
         if ctx.relu:  # relu'(pre-activation) from the saved output; with a 1-D bias its gradient comes out of the same pass
             if want_db and ctx.bias_kind == 1:
-                g, db = relu_bwd_colsum(g.contiguous(), y)
+                g, db = relu_bwd_colsum(g, y)
             else:
                 g = torch.ops.aten.threshold_backward(g, y, 0.0)
         g2 = g.reshape(-1, W.shape[0])
@@ -689,6 +712,120 @@ def linear(x, W, b=None, out=None, relu=False, consume_addend=False):
         assert out is None
         return _Linear.apply(x, W, b, relu, consume_addend)
     return _linear_fwd(x, W, b, out, relu, consume_addend)
+
+
+_gemm_lib = None
+_gemm_ws = {}
+
+
+def load_gemm_library():
+    """libmappo_gemm.so (include/mappo_gemm.h): the Linear GEMM with a strided output and a fused epilogue on hipBLASLt"""
+    global _gemm_lib
+    if _gemm_lib is None:
+        path = _build.lib_path("libmappo_gemm.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        Lg = C.CDLL(path)
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        Lg.mo_gemm_workspace_bytes.restype = i64
+        Lg.mo_gemm_nt.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, i32, vp, i64, vp, i64, vp]
+        _gemm_lib = Lg
+    return _gemm_lib
+
+
+def gemm_nt(x, W, bias=None, relu=False, out=None, addend=None):
+    """out = act(x W^T + bias + addend) for 2-D row-major x (rows, K), W (N, K), out / addend (rows, N); every matrix may be a
+    column block of a wider one (last stride 1, any row stride) -- the form torch's GEMM epilogue path cannot write.  No autograd."""
+    Lg = load_gemm_library()
+    _need_gpu(x, "gemm_nt")
+    M, K = x.shape
+    N = W.shape[0]
+    W = W.detach()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    for t in (x, W, out) + ((addend,) if addend is not None else ()):
+        assert t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.data_ptr() % 16 == 0
+    assert W.shape[1] == K and out.shape == (M, N) and (addend is None or addend.shape == (M, N))
+    b = bias.detach().contiguous() if bias is not None else None
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = _gemm_ws[key] = torch.empty(Lg.mo_gemm_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    rc = Lg.mo_gemm_nt(M, N, K, _ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), _ptr(addend), addend.stride(0) if addend is not None else 0,
+                       int(bool(relu)), _ptr(out), out.stride(0), _ptr(ws), ws.numel(), _stream())
+    if rc != 0:
+        raise RuntimeError(f"mo_gemm_nt failed (code {rc})")
+    return out
+
+
+def block2d(t):
+    """(rows, E) 2-D view of a dense tensor or of a column block of a dense matrix (see _vec_stride); never copies"""
+    E = t.shape[-1]
+    return t.as_strided((t.numel() // E, E), (_vec_stride(t), 1))
+
+
+class _FcraHop(torch.autograd.Function):
+    """One hop of DHGN.fcra (DHGN/mappo_parallel.py:204-233):  h' = relu([agg | h] Wf^T + bf),  agg = relu(nb Wagg^T + bagg).
+    The reference concatenates; rounds 1-2 ran the FCRA layer as two accumulating GEMMs followed by a separate ReLU pass (and its
+    backward as threshold + bias-sum passes).  Here [agg | h] is ONE (rows, 2E) operand that is never assembled by a copy: the AGG
+    GEMM writes its (bias + ReLU epilogue) result into the left half, the previous hop's FCRA GEMM wrote h into the right half
+    (`cat`: that buffer; None on the first hop, whose h is copied in), so the layer is one K = 2E GEMM with bias + ReLU in its
+    epilogue.  Backward: relu'/bias-gradient in one pass per layer (relu_bwd_colsum on column blocks), one GEMM for
+    [d agg | d h], split-K MFMA weight gradients.  nb is stored data (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, nb, h, cat, Wagg, bagg, Wf, bf, last, out, box):
+        E = Wf.shape[0]
+        rows = h.numel() // E
+        nb2 = nb.reshape(rows, E)
+        if cat is None:
+            cat = torch.empty((rows, 2 * E), dtype=h.dtype, device=h.device)
+            cat[:, E:].copy_(block2d(h))
+        else:
+            assert cat.shape == (rows, 2 * E) and cat.is_contiguous() and h.data_ptr() == cat.data_ptr() + E * cat.element_size()
+        gemm_nt(nb2, Wagg, bagg, True, out=cat[:, :E])
+        nxt = None
+        if out is not None:     # rollout: the caller's static storage (no autograd)
+            ctx.mark_dirty(out)
+            dst = block2d(out)
+        elif last:
+            dst = torch.empty((rows, E), dtype=h.dtype, device=h.device)
+        else:
+            nxt = torch.empty((rows, 2 * E), dtype=h.dtype, device=h.device)
+            dst = nxt[:, E:]
+        gemm_nt(cat, Wf, bf, True, out=dst)
+        box.append(nxt)
+        ctx.save_for_backward(nb2, Wagg, Wf)
+        # the two operand buffers are kept as plain references: the next hop writes the OTHER half of `nxt` in place, which bumps
+        # the version counter the saved view `dst` shares with it although its own columns are never touched again
+        ctx.cat, ctx.y = cat, dst
+        ctx.h_shape = h.shape
+        return dst.reshape(h.shape) if out is None else out
+
+    @staticmethod
+    def backward(ctx, g):
+        nb2, Wagg, Wf = ctx.saved_tensors
+        cat, y = ctx.cat, ctx.y
+        E = Wf.shape[0]
+        rows = cat.shape[0]
+        try:
+            g2 = block2d(g)
+        except AssertionError:
+            g2 = g.reshape(rows, E).contiguous()
+        gin, dbf = relu_bwd_colsum(g2, y)
+        dcat = torch.mm(gin, Wf)                       # [d agg | d h]
+        dWf = wgrad(gin, cat)
+        ga, dbagg = relu_bwd_colsum(dcat[:, :E], cat[:, :E])
+        dWagg = wgrad(ga, nb2)
+        d_h = dcat[:, E:].reshape(ctx.h_shape)         # a view (column block)
+        return None, d_h, None, dWagg, dbagg, dWf, dbf, None, None, None
+
+
+def fcra_hop(nb, h, cat, Wagg, bagg, Wf, bf, last, out=None):
+    """-> (h', cat'): see _FcraHop.  cat' is the buffer whose right half h' is (None after the last hop / when `out` is given)."""
+    box = []
+    y = _FcraHop.apply(nb, h, cat, Wagg, bagg, Wf, bf, bool(last), out, box)
+    return y, box[0]
 
 
 FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel

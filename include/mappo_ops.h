@@ -71,10 +71,11 @@ int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P
 /* The same launch, which also writes the position part of DHGN's semantic layer for these rows, pos[r][i][:] = bp + Wp p[r][i]
  * (Wp [E][4]: the first four input columns of semantic_layer.weight, wp_row_stride elements between its rows; mappo_parallel.py:
  * 284-303) -- the addend the embedding part of that layer accumulates into; the same numbers for both networks, written to
- * pos_actor and (if not NULL) pos_critic, dense [R][P][E]. */
+ * pos_actor and (if not NULL) pos_critic, [R][P] vectors of E floats, pos_stride (>= E) elements apart (E: dense; 2 E: the right
+ * half of a [R P][2 E] operand that a later layer reads as one concatenated input). */
 int dhgn_msg_agg3_pair_pos_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_row_stride,
                                const int32_t *o_kvalid, float *out_actor, float *out_critic, int64_t out_stride, const float *Wp,
-                               int64_t wp_row_stride, const float *bp, float *pos_actor, float *pos_critic, void *stream);
+                               int64_t wp_row_stride, const float *bp, float *pos_actor, float *pos_critic, int64_t pos_stride, void *stream);
 
 /*
  * Backward of the above w.r.t. W and b (the inputs are data, they carry no gradient): recomputes the
@@ -249,22 +250,25 @@ int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const
  *   actor (out_actor != NULL): abar = adj / max(sum_j |adj|, 1e-12), adj [R][P][P] (adj_row_stride elements between rows);
  *   critic (out_critic != NULL): abar = 1 / P (the normalised ones_like(adj) of AttributeDataset :64-65).
  * z_* are read in place from a (N, T', P, E) history buffer: row r = (n, t) = (r / T, r % T) starts at n * episode_stride +
- * t * step_stride (T = 1 and episode_stride = P E: a dense [R][P][E] tensor); bias [E] or NULL; out_* dense [R][P][E].
+ * t * step_stride (T = 1 and episode_stride = P E: a dense [R][P][E] tensor); bias [E] or NULL; out_*: [R][P] vectors of E floats,
+ * out_stride (>= E) elements apart (E: dense; 2 E: the left half of the [agg | h] operand of the FCRA layer, :227-231).
  * Either output may be NULL; both together serve the rollout's paired actor / critic tick.
  */
 int fcra_neighbour_mean(int32_t R, int32_t P, int32_t E, int32_t T, const float *z_actor, int64_t za_episode_stride, int64_t za_step_stride,
                         const float *z_critic, int64_t zc_episode_stride, int64_t zc_step_stride, const float *adj, int64_t adj_row_stride,
-                        const float *bias, int32_t relu, float *out_actor, float *out_critic, void *stream);
+                        const float *bias, int32_t relu, float *out_actor, float *out_critic, int64_t out_stride, void *stream);
 
 /*
  * ReLU backward and the bias gradient of the Linear in front of it in one pass (autograd: aten::threshold_backward, then
  * grad.sum(0) re-reading it; MAPPO.train's loss.backward(), DHGN/mappo_parallel.py:660-708):
  *   gin [R][F] = gout * [y > 0] (y = the saved ReLU output);  colsum [F] = sum_r gin[r][:].
- * Rows are F contiguous floats, F a multiple of 4 with F/4 dividing 256; 16-byte aligned pointers.  Deterministic
+ * Rows are F contiguous floats, g_row_stride / y_row_stride (>= F, multiples of 4) elements apart for gout / y (a column block of
+ * a wider matrix), dense for gin; F a multiple of 4 with F/4 dividing 256; 16-byte aligned pointers.  Deterministic
  * (per-workgroup partials in `workspace` >= relu_bwd_colsum_workspace(F) bytes, reduced in a fixed order in f64).
  */
 int64_t relu_bwd_colsum_workspace(int32_t F);
-int relu_bwd_colsum(int64_t R, int32_t F, const float *gout, const float *y, float *gin, float *colsum, void *workspace, void *stream);
+int relu_bwd_colsum(int64_t R, int32_t F, const float *gout, int64_t g_row_stride, const float *y, int64_t y_row_stride, float *gin, float *colsum,
+                    void *workspace, void *stream);
 
 /*
  * Weight gradient of a Linear layer with at most 16 inputs or outputs (the K = 4 position part of DHGN's semantic layer, the action

@@ -628,3 +628,37 @@ def test_rollout_heads_match_the_separate_kernels(R, A):
         assert R < 1000 or a_n.unique().numel() == A
         ops.head_sample(feat, W, b, 77, counter, ticket, (a_n, logp), greedy=True)
         assert torch.equal(a_n.long(), prob.argmax(-1)) or (a_n.long() != prob.argmax(-1)).float().mean().item() < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(61500 * 8, 128, 256), (1000, 128, 128), (7, 128, 384)])
+@pytest.mark.parametrize("bias,relu,addend", [(True, True, False), (True, False, False), (False, False, True), (False, True, False), (True, True, True)])
+def test_gemm_nt_strided_output_and_epilogues_match_torch(M, N, K, bias, relu, addend):
+    """ops.gemm_nt (include/mappo_gemm.h, hipBLASLt): out = act(x W^T + bias + addend) written into a column block of a wider
+    matrix, x itself a column block -- against F.linear in fp32 (GEMM reordering tolerance); the other columns stay untouched."""
+    import torch.nn.functional as F
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(K + N)
+    if M > 100000:
+        M = M // 4
+    xw = torch.randn(M, K + 128, device="cuda")
+    x = xw[:, 128:]                                   # column block, row stride K + 128
+    W = torch.randn(N, K, device="cuda") * 0.1
+    b = torch.randn(N, device="cuda") if bias else None
+    wide = torch.full((M, 2 * N), 7.0, device="cuda")
+    out = wide[:, N:]
+    add = None
+    if addend:
+        out.copy_(torch.randn(M, N, device="cuda"))
+        add = out                                     # accumulate in place (beta = 1)
+    ref = F.linear(x, W, b)
+    if addend:
+        ref = ref + out
+    if relu:
+        ref = torch.relu(ref)
+    got = ops.gemm_nt(x, W, b, relu, out=out, addend=add)
+    assert got.data_ptr() == out.data_ptr()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    assert bool((wide[:, :N] == 7.0).all())
+    dense = ops.gemm_nt(x.contiguous(), W, b, relu) if not addend else None
+    if dense is not None:
+        assert torch.allclose(dense, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
