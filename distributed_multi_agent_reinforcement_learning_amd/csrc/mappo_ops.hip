@@ -1184,9 +1184,16 @@ __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, const float *
 constexpr int GRU2_LD = 36, GRU2_LD3 = 100;   // floats per (plane, row): 32 (96) operand slots + 4 pad, rows stay 16-byte aligned
 __device__ __forceinline__ int gru2_hidx(int row, int k) { return ((k >> 5) * GRU_RB + row) * GRU2_LD + (k & 31); }
 
-__global__ __launch_bounds__(512) void k_gru_seq_fwd2(int T, int B, const float *__restrict__ gi, const float *__restrict__ w_hh,
-                                                      const float *__restrict__ b_hh, const float *__restrict__ h0, float *__restrict__ out,
-                                                      float *__restrict__ save, int gi_agents) {
+// Several independent layers of the same shape (the actor's and the critic's: different weights, same T and B) run as ONE launch:
+// blockIdx.y selects the layer.  At the benchmark's mini-batch a layer is 205 workgroups; at a data-parallel rank's share (26-103
+// workgroups) a layer alone leaves most CUs idle for T sequential steps, and the launch takes as long as at full size.
+struct GruFwdNets { mo_gru_seq_net n[MO_GRU_MAX_NETS]; };
+struct GruBwdNets { mo_gru_seq_bwd_net n[MO_GRU_MAX_NETS]; };
+
+__global__ __launch_bounds__(512) void k_gru_seq_fwd2(int T, int B, GruFwdNets nets, int gi_agents) {
+    const mo_gru_seq_net &net = nets.n[blockIdx.y];
+    const float *__restrict__ gi = net.gi, *__restrict__ w_hh = net.w_hh, *__restrict__ b_hh = net.b_hh, *__restrict__ h0 = net.h0;
+    float *__restrict__ out = net.out, *__restrict__ save = net.save;
     __shared__ __attribute__((aligned(16))) float hs[2][4 * GRU_RB * GRU2_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int b0 = blockIdx.x * GRU_RB;
@@ -1257,10 +1264,12 @@ __global__ __launch_bounds__(512) void k_gru_seq_fwd2(int T, int B, const float 
     }
 }
 
-__global__ __launch_bounds__(512) void k_gru_seq_bwd2(int T, int B, const float *__restrict__ dout, const float *__restrict__ save,
-                                                      const float *__restrict__ out, const float *__restrict__ h0, const float *__restrict__ w_hh,
-                                                      float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dnr_out,
-                                                      float *__restrict__ dh0, float *__restrict__ bias_partials, int gi_agents) {
+__global__ __launch_bounds__(512) void k_gru_seq_bwd2(int T, int B, GruBwdNets nets, int gi_agents) {
+    const mo_gru_seq_bwd_net &net = nets.n[blockIdx.y];
+    const float *__restrict__ dout = net.dout, *__restrict__ save = net.save, *__restrict__ out = net.out, *__restrict__ h0 = net.h0,
+                *__restrict__ w_hh = net.w_hh;
+    float *__restrict__ dgi = net.dgi, *__restrict__ dgh = net.dgh, *__restrict__ dnr_out = net.dnr, *__restrict__ dh0 = net.dh0;
+    float *__restrict__ bias_partials = net.db_ih ? (float *)net.workspace : nullptr;
     __shared__ __attribute__((aligned(16))) float gs[2][4 * GRU_RB * GRU2_LD3];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int b0 = blockIdx.x * GRU_RB;
@@ -2100,32 +2109,55 @@ int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, cons
 
 int64_t gru_seq_save_elems(int32_t T, int32_t B) { return (int64_t)T * ((B + GRU_RB - 1) / GRU_RB) * 4 * 512 * 4; }
 
+int gru_seq_fwd_multi(int32_t n_nets, const mo_gru_seq_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream) {
+    if (n_nets < 1 || n_nets > MO_GRU_MAX_NETS || !nets || T < 1 || B < 1 || H != GRU_H || gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
+    GruFwdNets a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < n_nets; k++) {
+        const mo_gru_seq_net &m = nets[k];
+        if (!m.gi || !m.w_hh || !m.b_hh || !m.h0 || !m.out) return MO_ERR_BAD_ARG;
+        if ((((uintptr_t)m.gi | (uintptr_t)m.w_hh | (uintptr_t)m.b_hh | (uintptr_t)m.h0 | (uintptr_t)m.out | (uintptr_t)m.save) & 15)) return MO_ERR_BAD_ARG;
+        a.n[k] = m;
+    }
+    const int nblk = (B + GRU_RB - 1) / GRU_RB;
+    hipLaunchKernelGGL(k_gru_seq_fwd2, dim3(nblk, n_nets), dim3(512), 0, (hipStream_t)stream, T, B, a, (int)gi_agents);
+    return (int)hipGetLastError();
+}
+
 int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
                 float *save, int32_t gi_agents, void *stream) {
-    if (T < 1 || B < 1 || H != GRU_H || !gi || !w_hh || !b_hh || !h0 || !out || gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
-    if ((((uintptr_t)gi | (uintptr_t)w_hh | (uintptr_t)b_hh | (uintptr_t)h0 | (uintptr_t)out | (uintptr_t)save) & 15)) return MO_ERR_BAD_ARG;
-    const int nblk = (B + GRU_RB - 1) / GRU_RB;
-    hipLaunchKernelGGL(k_gru_seq_fwd2, dim3(nblk), dim3(512), 0, (hipStream_t)stream, T, B, gi, w_hh, b_hh, h0, out, save, (int)gi_agents);
-    return (int)hipGetLastError();
+    const mo_gru_seq_net net{gi, w_hh, b_hh, h0, out, save};
+    return gru_seq_fwd_multi(1, &net, T, B, H, gi_agents, stream);
 }
 
 int64_t gru_seq_bwd_workspace(int32_t B) { return (int64_t)((B + GRU_RB - 1) / GRU_RB) * 4 * GRU_H * sizeof(float); }
 
+int gru_seq_bwd_multi(int32_t n_nets, const mo_gru_seq_bwd_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream) {
+    if (n_nets < 1 || n_nets > MO_GRU_MAX_NETS || !nets || T < 1 || B < 1 || H != GRU_H || gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
+    GruBwdNets a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < n_nets; k++) {
+        const mo_gru_seq_bwd_net &m = nets[k];
+        if (!m.dout || !m.save || !m.out || !m.h0 || !m.w_hh || !m.dgi || !m.dh0) return MO_ERR_BAD_ARG;
+        if ((m.dgh == nullptr) == (m.dnr == nullptr)) return MO_ERR_BAD_ARG;        // exactly one of the two forms
+        if ((m.db_ih || m.db_hh) && (!m.db_ih || !m.db_hh || !m.workspace)) return MO_ERR_BAD_ARG;
+        if ((((uintptr_t)m.dout | (uintptr_t)m.save | (uintptr_t)m.out | (uintptr_t)m.h0 | (uintptr_t)m.dgi | (uintptr_t)m.dgh | (uintptr_t)m.dnr |
+              (uintptr_t)m.dh0 | (uintptr_t)m.workspace) & 15)) return MO_ERR_BAD_ARG;
+        a.n[k] = m;
+    }
+    const int nblk = (B + GRU_RB - 1) / GRU_RB;
+    hipLaunchKernelGGL(k_gru_seq_bwd2, dim3(nblk, n_nets), dim3(512), 0, (hipStream_t)stream, T, B, a, (int)gi_agents);
+    for (int k = 0; k < n_nets; k++)
+        if (nets[k].db_ih)
+            hipLaunchKernelGGL(k_gru_bias_reduce, dim3(4 * GRU_H / 4), dim3(256), 0, (hipStream_t)stream, nblk, (const float *)nets[k].workspace, nets[k].db_ih,
+                               nets[k].db_hh);
+    return (int)hipGetLastError();
+}
+
 int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0, const float *w_hh,
                 float *dgi, float *dgh, float *dnr, float *dh0, float *db_ih, float *db_hh, int32_t gi_agents, void *workspace, void *stream) {
-    if (T < 1 || B < 1 || H != GRU_H || !dout || !save || !out || !h0 || !w_hh || !dgi || !dh0) return MO_ERR_BAD_ARG;
-    if ((dgh == nullptr) == (dnr == nullptr)) return MO_ERR_BAD_ARG;        // exactly one of the two forms
-    if (gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
-    if ((db_ih || db_hh) && (!db_ih || !db_hh || !workspace)) return MO_ERR_BAD_ARG;
-    if ((((uintptr_t)dout | (uintptr_t)save | (uintptr_t)out | (uintptr_t)h0 | (uintptr_t)dgi | (uintptr_t)dgh | (uintptr_t)dnr | (uintptr_t)dh0 |
-          (uintptr_t)workspace) & 15)) return MO_ERR_BAD_ARG;
-    const int nblk = (B + GRU_RB - 1) / GRU_RB;
-    float *bp = db_ih ? (float *)workspace : (float *)nullptr;
-    hipLaunchKernelGGL(k_gru_seq_bwd2, dim3(nblk), dim3(512), 0, (hipStream_t)stream, T, B, dout, save, out, h0, w_hh, dgi, dgh, dnr, dh0, bp,
-                       (int)gi_agents);
-    if (db_ih)
-        hipLaunchKernelGGL(k_gru_bias_reduce, dim3(4 * GRU_H / 4), dim3(256), 0, (hipStream_t)stream, nblk, (const float *)workspace, db_ih, db_hh);
-    return (int)hipGetLastError();
+    const mo_gru_seq_bwd_net net{dout, save, out, h0, w_hh, dgi, dgh, dnr, dh0, db_ih, db_hh, workspace};
+    return gru_seq_bwd_multi(1, &net, T, B, H, gi_agents, stream);
 }
 
 int64_t wgrad_tn_workspace(int32_t M, int32_t N) {

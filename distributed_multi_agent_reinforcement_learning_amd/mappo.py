@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .model import build_actor_critic
+from .model import build_actor_critic, sequence_forward_pair
 from .pe_env import status_or, status_text
 
 BUFFER_KEYS = ("p_state", "e_state", "o_state", "p_adj", "e_adj", "o_adj", "actor_historical_embedding",
@@ -199,8 +199,11 @@ class MAPPO:
             # One stream: running the critic branch beside the actor's on a second stream was tried in round 1 and removed --
             # it put two library GEMMs in flight at once, and with DHGN depth > 0 at 4096 environments the update stopped making
             # progress ("two-stream update").  A whole-device library GEMM is not a kernel to co-schedule.
-            a_logprob_n_now, dist_entropy = self.actor.get_logprob_and_entropy(obs, hist_a, batch["a_n"][n0:n1], mb, T)
-            values_now = self.critic(obs, hist_c, None, 1, mb, T).squeeze(-1)
+            # actor and critic together: their GRU recurrences share one launch per layer and direction (model.sequence_forward_pair)
+            prob, values_now = sequence_forward_pair(self.actor, self.critic, obs, hist_a, hist_c, mb, T)
+            dist = torch.distributions.Categorical(prob)      # get_logprob_and_entropy (:451-456)
+            a_logprob_n_now, dist_entropy = dist.log_prob(batch["a_n"][n0:n1]), dist.entropy()
+            values_now = values_now.squeeze(-1)
             actor_loss, critic_loss = ops.ppo_loss(a_logprob_n_now, dist_entropy, values_now, batch["a_logprob_n"][n0:n1], adv[n0:n1],
                                                    batch["active"][n0:n1], batch["v_n"][n0:n1, :-1] if self.use_value_clip else None,
                                                    v_target[n0:n1], self.epsilon, self.entropy_coef, self.use_value_clip)

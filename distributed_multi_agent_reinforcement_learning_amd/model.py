@@ -290,6 +290,27 @@ class SharedCritic(_Trunk):
         return self.Mean(feat).permute(1, 0, 2, 3)
 
 
+def sequence_forward_pair(actor, critic, obs, hist_a, hist_c, batch, steps):
+    """SharedActor.forward(mode 1) and SharedCritic.forward(mode 1) of one mini-batch together (DHGN/mappo_parallel.py:426-437,
+    :503-520): the two encoders as before, then the two GRUs layer by layer with actor and critic in ONE persistent launch each way
+    (ops.gru_multi) -- same numbers as the two module calls.  -> (prob (batch, steps, P, A), values (batch, steps, P, 1))."""
+    emb_a = actor.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_a, False, None,
+                             obs.get("q_div", 1), None)
+    emb_c = critic.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_c, True, None,
+                              obs.get("q_div", 1), None)
+    P = emb_a.shape[1]
+    if not (actor.use_rnn and critic.use_rnn):
+        feat_a, feat_c = actor._sequence_features(emb_a, batch, steps), critic._sequence_features(emb_c, batch, steps)
+    else:
+        h0 = [torch.zeros(m.num_layers, batch * P, m.rnn_hidden_dim, dtype=emb_a.dtype, device=emb_a.device) for m in (actor, critic)]
+        fa, fc = ops.gru_multi([emb_a.reshape(batch * steps * P, actor.rnn_input_dim), emb_c.reshape(batch * steps * P, critic.rnn_input_dim)],
+                               h0, [actor.GRU, critic.GRU], agents=P, steps=steps)
+        feat_a, feat_c = fa.reshape(steps, batch, P, actor.rnn_hidden_dim), fc.reshape(steps, batch, P, critic.rnn_hidden_dim)
+    prob = torch.softmax(actor.Mean(feat_a), dim=-1).permute(1, 0, 2, 3)
+    values = critic.Mean(feat_c).permute(1, 0, 2, 3)
+    return prob, values
+
+
 def build_actor_critic(cfg, device):
     """encoder -> actor -> critic, the construction order of MAPPO.__init__ (:582-616); encoder is shared."""
     sn = cfg.algo.use_spectral_norm

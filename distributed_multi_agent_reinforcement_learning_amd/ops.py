@@ -15,7 +15,7 @@ ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -57,6 +57,8 @@ def load_library():
         L.gru_cell_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
         L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+        L.gru_seq_fwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
+        L.gru_seq_bwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_save_elems.argtypes = [i32, i32]
         L.gru_seq_save_elems.restype = i64
         L.gru_seq_bwd_workspace.argtypes = [i32]
@@ -975,18 +977,7 @@ class _GRULayer(torch.autograd.Function):
                 _check(L.gru_gates_bwd(B, H, _ptr(dout[t]), _ptr(dcarry), _ptr(save[t]), _ptr(hprev), _ptr(dgi3[t]), _ptr(dgh[t]),
                                        _ptr(dh_direct), st), "gru_gates_bwd")
                 dcarry = torch.addmm(dh_direct, dgh[t], w_hh)
-        if split:
-            dw_hh = torch.empty((3 * H, H), dtype=x.dtype, device=x.device)
-            drz, hp = dgi[:, :2 * H], out[:-1].reshape((T - 1) * B, H)     # (dr, dz): a column slice of dgi, rows strided, no copy
-            torch.mm(drz[:B].t(), h0, out=dw_hh[:2 * H])
-            torch.mm(dnr[0].t(), h0, out=dw_hh[2 * H:])
-            if T > 1:
-                wgrad(drz[B:], hp, out=dw_hh[:2 * H], accumulate=True)
-                wgrad(dnr[1:].reshape((T - 1) * B, H), hp, out=dw_hh[2 * H:], accumulate=True)
-        else:
-            dw_hh = torch.mm(dgh[0].t(), h0)
-            if T > 1:
-                wgrad(dgh[1:].reshape((T - 1) * B, 3 * H), out[:-1].reshape((T - 1) * B, H), out=dw_hh, accumulate=True)
+        dw_hh = _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H)
         x2 = x.reshape(T * B, I)
         dw_ih = wgrad(dgi, x2)
         dx = None
@@ -999,6 +990,141 @@ class _GRULayer(torch.autograd.Function):
         if db_ih is None:
             db_ih, db_hh = dgi.sum(0), dgh.reshape(T * B, 3 * H).sum(0)
         return dx, dcarry, dw_ih, dw_hh, db_ih, db_hh, None, None, None
+
+
+GRU_MULTI_MAX_WORKGROUPS = 256   # CUs of an MI355X: one persistent workgroup each
+
+
+class GruSeqNet(C.Structure):
+    """include/mappo_ops.h mo_gru_seq_net"""
+    _fields_ = [(n, C.c_void_p) for n in ("gi", "w_hh", "b_hh", "h0", "out", "save")]
+
+
+class GruSeqBwdNet(C.Structure):
+    """include/mappo_ops.h mo_gru_seq_bwd_net"""
+    _fields_ = [(n, C.c_void_p) for n in ("dout", "save", "out", "h0", "w_hh", "dgi", "dgh", "dnr", "dh0", "db_ih", "db_hh", "workspace")]
+
+
+class _GRULayerMulti(torch.autograd.Function):
+    """The same layer of several independent GRUs (the actor's and the critic's: own weights, own inputs, same T, B and row order)
+    with the recurrences of all of them in ONE persistent launch each way (gru_seq_fwd_multi / gru_seq_bwd_multi); per network the
+    arithmetic is that of _GRULayer's persistent path.  args: T, B, agents, then per network (x, h0, w_ih, w_hh, b_ih, b_hh)."""
+
+    @staticmethod
+    def forward(ctx, T, B, agents, *ts):
+        L = load_library()
+        n = len(ts) // 6
+        H = ts[3].shape[1]
+        assert H == 128 and T >= PERSISTENT_GRU_MIN_T and len(ts) == 6 * n
+        need = any(ctx.needs_input_grad)
+        outs, saved = [], []
+        arr = (GruSeqNet * n)()
+        keep = []
+        for k in range(n):
+            x, h0, w_ih, w_hh, b_ih, b_hh = ts[6 * k: 6 * k + 6]
+            _need_gpu(x, "gru")
+            I = x.shape[-1]
+            x, h0 = x.contiguous(), h0.contiguous()
+            out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
+            gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())
+            save = torch.empty(L.gru_seq_save_elems(T, B), dtype=x.dtype, device=x.device) if need else None
+            whh, bhh = w_hh.detach().contiguous(), b_hh.detach().contiguous()
+            a = arr[k]
+            a.gi, a.w_hh, a.b_hh, a.h0, a.out = gi.data_ptr(), whh.data_ptr(), bhh.data_ptr(), h0.data_ptr(), out.data_ptr()
+            a.save = save.data_ptr() if need else None
+            keep.append((gi, whh, bhh))
+            outs.append(out)
+            saved += [x, h0, w_ih, whh, out, save]
+        _check(L.gru_seq_fwd_multi(n, C.cast(arr, C.c_void_p), T, B, H, int(agents), _stream()), "gru_seq_fwd_multi")
+        ctx.dims, ctx.agents, ctx.n = (T, B), int(agents), n
+        ctx.x_shapes = [ts[6 * k].shape for k in range(n)]
+        if need:
+            ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        L = load_library()
+        T, B = ctx.dims
+        n = ctx.n
+        sv = ctx.saved_tensors
+        H = 128
+        split = not ctx.agents      # time-major dgi rows: dr, dz stored once (see _GRULayer.backward)
+        arr = (GruSeqBwdNet * n)()
+        per = []
+        for k in range(n):
+            x, h0, w_ih, w_hh, out, save = sv[6 * k: 6 * k + 6]
+            dev, dt = x.device, x.dtype
+            dout = douts[k].contiguous()
+            dgi = torch.empty((T * B, 3 * H), dtype=dt, device=dev)
+            dgh = None if split else torch.empty((T, B, 3 * H), dtype=dt, device=dev)
+            dnr = torch.empty((T, B, H), dtype=dt, device=dev) if split else None
+            dh0 = torch.empty((B, H), dtype=dt, device=dev)
+            db_ih, db_hh = torch.empty(3 * H, dtype=dt, device=dev), torch.empty(3 * H, dtype=dt, device=dev)
+            ws = torch.empty(L.gru_seq_bwd_workspace(B), dtype=torch.uint8, device=dev)
+            a = arr[k]
+            a.dout, a.save, a.out, a.h0, a.w_hh, a.dgi = dout.data_ptr(), save.data_ptr(), out.data_ptr(), h0.data_ptr(), w_hh.data_ptr(), dgi.data_ptr()
+            a.dgh = dgh.data_ptr() if dgh is not None else None
+            a.dnr = dnr.data_ptr() if dnr is not None else None
+            a.dh0, a.db_ih, a.db_hh, a.workspace = dh0.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), ws.data_ptr()
+            per.append((dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws))
+        _check(L.gru_seq_bwd_multi(n, C.cast(arr, C.c_void_p), T, B, H, ctx.agents, _stream()), "gru_seq_bwd_multi")
+        grads = [None, None, None]
+        for k in range(n):
+            x, h0, w_ih, w_hh, out, save = sv[6 * k: 6 * k + 6]
+            dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws = per[k]
+            dw_hh = _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H)
+            I = x.shape[-1]
+            dw_ih = wgrad(dgi, x.reshape(T * B, I))
+            dx = torch.mm(dgi, w_ih).reshape(ctx.x_shapes[k]) if ctx.needs_input_grad[3 + 6 * k] else None
+            grads += [dx, dh0, dw_ih, dw_hh, db_ih, db_hh]
+        return tuple(grads)
+
+
+def _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H):
+    """dW_hh = [dr dz dnr]^T h_prev over all steps: from the full time-major dgh, or (dr, dz stored once) from dgi's first 2H
+    columns and dnr"""
+    if dgh is not None:
+        dw_hh = torch.mm(dgh[0].t(), h0)
+        if T > 1:
+            wgrad(dgh[1:].reshape((T - 1) * B, 3 * H), out[:-1].reshape((T - 1) * B, H), out=dw_hh, accumulate=True)
+        return dw_hh
+    dw_hh = torch.empty((3 * H, H), dtype=dgi.dtype, device=dgi.device)
+    drz, hp = dgi[:, :2 * H], out[:-1].reshape((T - 1) * B, H)     # (dr, dz): a column slice of dgi, rows strided, no copy
+    torch.mm(drz[:B].t(), h0, out=dw_hh[:2 * H])
+    torch.mm(dnr[0].t(), h0, out=dw_hh[2 * H:])
+    if T > 1:
+        wgrad(drz[B:], hp, out=dw_hh[:2 * H], accumulate=True)
+        wgrad(dnr[1:].reshape((T - 1) * B, H), hp, out=dw_hh[2 * H:], accumulate=True)
+    return dw_hh
+
+
+def gru_multi(xs, h0s, modules, agents=0, steps=None):
+    """ops.gru for several independent GRU modules of one shape on inputs of one shape (actor and critic): layer by layer, the
+    recurrences of all modules in one launch (see _GRULayerMulti).  Returns the list of outputs (T, B, H) (no h_n: sequences start
+    from the given h0 and the final state is out[-1]).  Shapes the persistent kernels do not cover take ops.gru per module."""
+    n = len(xs)
+    x0 = xs[0]
+    if agents:
+        assert x0.dim() == 2 and steps and x0.shape[0] % (steps * agents) == 0
+        T, B = int(steps), x0.shape[0] // int(steps)
+    else:
+        T, B = x0.shape[0], x0.shape[1]
+    # one launch only while all layers' workgroups (16 rows each) are resident at once: at the full benchmark mini-batch (205 + 205
+    # workgroups on 256 CUs) the second layer's workgroups would queue behind the first's anyway and the extra concurrency only adds
+    # HBM contention (measured: update +13 ms at 4096 environments, -16 ms at 512)
+    ok = (n <= 4 and T >= PERSISTENT_GRU_MIN_T and all(x.shape == x0.shape for x in xs) and n * ((B + 15) // 16) <= GRU_MULTI_MAX_WORKGROUPS
+          and all(m.num_layers == modules[0].num_layers and m.weight_hh_l0.shape == (384, 128) for m in modules))
+    if not ok:
+        return [gru(x, h0, m, agents=agents, steps=steps)[0] for x, h0, m in zip(xs, h0s, modules)]
+    inps = list(xs)
+    for layer in range(modules[0].num_layers):
+        ts = []
+        for k, m in enumerate(modules):
+            ts += [inps[k], h0s[k][layer], getattr(m, f"weight_ih_l{layer}"), getattr(m, f"weight_hh_l{layer}"),
+                   getattr(m, f"bias_ih_l{layer}"), getattr(m, f"bias_hh_l{layer}")]
+        inps = list(_GRULayerMulti.apply(T, B, int(agents) if layer == 0 else 0, *ts))
+    return inps
 
 
 def gru(x, h0, gru_module, inplace_hidden=False, agents=0, steps=None):

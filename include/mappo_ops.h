@@ -181,6 +181,19 @@ int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, 
  * All pointers 16-byte aligned.
  */
 int64_t gru_seq_save_elems(int32_t T, int32_t B);
+/* Several independent layers of one shape in ONE launch (the actor's and the critic's layer of the same depth: different weights and
+ * inputs, same T, B, gi_agents): at a data-parallel rank's share of the batch one layer is a few dozen workgroups that run T sequential
+ * steps, and a launch takes as long as at full size; together the layers fill more of the chip in the same time.  Records of HOST
+ * memory holding DEVICE pointers, meaning as in gru_seq_fwd / gru_seq_bwd. */
+#define MO_GRU_MAX_NETS 4
+typedef struct mo_gru_seq_net { const float *gi, *w_hh, *b_hh, *h0; float *out, *save; } mo_gru_seq_net;
+typedef struct mo_gru_seq_bwd_net {
+    const float *dout, *save, *out, *h0, *w_hh;
+    float *dgi, *dgh, *dnr, *dh0, *db_ih, *db_hh;
+    void *workspace;   /* >= gru_seq_bwd_workspace(B) bytes when db_ih / db_hh are requested; one per record */
+} mo_gru_seq_bwd_net;
+int gru_seq_fwd_multi(int32_t n_nets, const mo_gru_seq_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream);
+int gru_seq_bwd_multi(int32_t n_nets, const mo_gru_seq_bwd_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream);
 int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
                 float *save, int32_t gi_agents, void *stream);
 int64_t gru_seq_bwd_workspace(int32_t B);
