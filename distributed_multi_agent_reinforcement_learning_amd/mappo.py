@@ -151,7 +151,9 @@ class MAPPO:
         self.actor, self.critic = build_actor_critic(cfg, self.device)
         enc = self.actor.shared_net
         # same parameter order as the reference's ac_parameters (:631): Adam state / clip_grad_norm_ follow it
-        self.ac_parameters = (list(enc.parameters()) + list(self.actor.GRU.parameters()) + list(self.critic.GRU.parameters())
+        # (algo.encoder=gnn_extractor: one encoder per network, the critic's follows the actor's)
+        enc_params = list(enc.parameters()) + ([] if self.critic.shared_net is enc else list(self.critic.shared_net.parameters()))
+        self.ac_parameters = (enc_params + list(self.actor.GRU.parameters()) + list(self.critic.GRU.parameters())
                               + list(self.critic.Mean.parameters()) + list(self.actor.Mean.parameters()))
         self.ac_optimizer = torch.optim.Adam(self.ac_parameters, lr=self.lr, eps=1e-5)
         self.minibuffer = None
@@ -267,11 +269,11 @@ class MAPPO:
         for t in range(T):
             items = [(st.obs[k], buf[k][rows, t]) for k in obs_keys]   # the policy program only reads st.obs
             if actions_override is not None:
-                st.policy_step(actions_override[rows, t].to(self.device).long())
+                st.step(actions_override[rows, t].to(self.device).long())
             elif use_graph:
                 st.replay_policy_step()
             else:
-                st.policy_step()
+                st.step()
             items += [(st.v, buf["v_n"][rows, t]), (st.a_n, buf["a_n"][rows, t]),      # int32 -> float32 like the reference buffer
                       (st.logp, buf["a_logprob_n"][rows, t])]
             if d or self.record_unused_embeddings:  # the update reads the stored embeddings as FCRA history only (EmbeddingDataset2, :95-113)
@@ -304,7 +306,12 @@ class MAPPO:
 
 
 class _RolloutState:
-    """Static device storage of one lockstep rollout and the per-tick policy program on it."""
+    """Static device storage of one lockstep rollout and the per-tick policy program on it.
+
+    History (FCRA hops): the embeddings of the last ticks live in a RING of pair slots `ring[M][2]` (slot t % M holds tick t's actor
+    [0] and critic [1] embedding, written there directly by the forward pass), and a hop is a reference to a slot -- nothing is
+    shifted or copied per tick (rounds 1-2 copied three (N, P, E) tensors per tick).  The addresses a tick reads and writes depend
+    on t % M only, so the captured per-tick program is one hipGraph per phase (M = 3 at depth 3 with the shared-history quirk)."""
 
     def __init__(self, agent, env):
         self.agent = agent
@@ -319,24 +326,38 @@ class _RolloutState:
         self.o_state = z(N, O, 4)
         self.o_kvalid = torch.zeros(N, dtype=torch.int32, device=dev)
         self.ha, self.hc = z(L, N * P, H), z(L, N * P, H)
-        quirk = agent.reference_quirks
-        self.hist = z(max(d, 1), N, P, E)                    # shared list, hop k = hist[k]
-        self.hist_c = None if quirk else z(max(d, 1), N, P, E)  # clean mode: actor uses hist, critic hist_c
-        self.ac_cur = z(2, N, P, E)                          # this tick's embeddings: slot 0 actor, slot 1 critic
-        self.a_cur, self.c_cur = self.ac_cur[0], self.ac_cur[1]
+        # the shared history list is a quirk of the DHGN agent's rollout; separate encoders keep their own histories
+        self.quirk = bool(agent.reference_quirks and agent.actor.shared_net is agent.critic.shared_net)
+        # quirk: the list is (.., a_{t-1}, c_{t-1}) for BOTH networks -- two entries per tick, so d hops reach ceil(d / 2) ticks back;
+        # clean: every network reads its own last d embeddings.  One more slot for the tick being written.
+        self.M = ((d + 1) // 2 if self.quirk else d) + 1
+        self.ring = z(self.M, 2, N, P, E)
+        self.t = 0                                            # policy steps taken in this episode (host counter: selects the phase)
         self.a_n = torch.zeros((N, P), dtype=torch.int32, device=dev)
         self.logp, self.v, self.raw = z(N, P), z(N, P), z(N, P)
         self.counter = torch.full((1,), int(agent.sample_rank) << 40, dtype=torch.int64, device=dev)  # position in the sampling stream (persists)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # scratch of ops.head_sample (left zero by every launch)
-        self.graph = None
+        self.graphs = {}                                      # phase (t % M) -> captured tick program
         # one encoder pass per tick for both networks (DHGN.forward_pair): they hold the same DHGN instance (:582-616)
         self.pair_forward = agent.actor.shared_net is agent.critic.shared_net
 
+    # the embeddings of the tick most recently computed (what the rollout records into the buffer)
+    @property
+    def a_cur(self):
+        return self.ring[(self.t - 1) % self.M][0]
+
+    @property
+    def c_cur(self):
+        return self.ring[(self.t - 1) % self.M][1]
+
+    @property
+    def hist_c(self):   # kept for callers that ask whether the networks keep separate histories
+        return None if self.quirk else self.ring[:, 1]
+
     def reset(self, env):
-        for t in (self.ha, self.hc, self.hist, self.a_cur, self.c_cur):
+        for t in (self.ha, self.hc, self.ring):
             t.zero_()
-        if self.hist_c is not None:
-            self.hist_c.zero_()
+        self.t = 0
         self.o_state.copy_(env.boundary_map.obstacle_agent)
         self.o_kvalid.copy_(env.n_obs)
 
@@ -345,33 +366,27 @@ class _RolloutState:
         o["o_state"], o["o_kvalid"] = self.o_state, self.o_kvalid
         return o
 
-    @staticmethod
-    def _shift(h, new_items):
-        """history list update: h[k] = hop k.  new_items are the most recent embeddings, newest first."""
-        d, n = h.shape[0], len(new_items)
-        for k in range(d - 1, n - 1, -1):
-            h[k].copy_(h[k - n])
-        for k in range(min(n, d)):
-            h[k].copy_(new_items[k])
+    def _hops(self, t):
+        """(hops_a, hops_c) for the forward pass of tick t: hop k = the k-th most recent entry of the history list.  Slots of ticks
+        before the episode's first are still zero (the reference starts from zero embeddings, :749-753)."""
+        d, M, ring = self.d, self.M, self.ring
+        if self.quirk:   # (.., a_{t-1}, c_{t-1}): hop 0 = c_{t-1}, hop 1 = a_{t-1}, hop 2 = c_{t-2}, ...
+            hops = [ring[(t - 1 - j // 2) % M][1 - j % 2] for j in range(d)]
+            return hops, hops
+        return [ring[(t - 1 - k) % M][0] for k in range(d)], [ring[(t - 1 - k) % M][1] for k in range(d)]
 
     def policy_step(self, forced_actions=None):
-        ag, d = self.agent, self.d
-        if d:
-            if self.hist_c is None:      # (.., a_{t-1}, c_{t-1}): hop 0 = c_{t-1}, hop 1 = a_{t-1}, hop k = old hop k-2
-                self._shift(self.hist, [self.c_cur, self.a_cur])
-                hops_a = hops_c = [self.hist[k] for k in range(d)]
-            else:
-                self._shift(self.hist, [self.a_cur])
-                self._shift(self.hist_c, [self.c_cur])
-                hops_a, hops_c = [self.hist[k] for k in range(d)], [self.hist_c[k] for k in range(d)]
-        else:
-            hops_a = hops_c = []
+        """the tick program of tick self.t (the caller advances self.t afterwards: step() / replay_policy_step())"""
+        ag = self.agent
+        hops_a, hops_c = self._hops(self.t)
+        slot = self.ring[self.t % self.M]                    # this tick's embeddings land here
+        a_cur, c_cur = slot[0], slot[1]
         o = self._obs()
         # every result lands directly in the static rollout storage (no copies behind the model)
         if self.pair_forward and not torch.is_grad_enabled():
             # one encoder pass for both networks (they hold the same DHGN instance), then the two GRU trunks and heads
             emb = ag.actor.shared_net.forward_pair(o["p_state"], o["e_state"], o["o_state"], o["p_adj"], o["e_adj"], o["o_adj_bits"],
-                                                   hops_a, hops_c, o["o_kvalid"], 1, self.ac_cur)
+                                                   hops_a, hops_c, o["o_kvalid"], 1, slot)
             a_emb, c_emb = emb[0], emb[1]
             feat_a, ha = ag.actor._rollout_features(a_emb, self.ha, True)
             feat_c, hc = ag.critic._rollout_features(c_emb, self.hc, True)
@@ -385,8 +400,8 @@ class _RolloutState:
             else:
                 prob = torch.softmax(ag.actor.head(feat_a), dim=-1)
         else:
-            prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True, emb_out=self.a_cur)
-            v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True, emb_out=self.c_cur)
+            prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True, emb_out=a_cur)
+            v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True, emb_out=c_cur)
         if forced_actions is not None:
             self.a_n.copy_(forced_actions.to(torch.int32))
             self.logp.copy_(torch.distributions.Categorical(probs=prob).log_prob(forced_actions))
@@ -396,32 +411,43 @@ class _RolloutState:
             self.ha.copy_(ha)
         if hc is not self.hc:
             self.hc.copy_(hc)
-        if a_emb.data_ptr() != self.a_cur.data_ptr():
-            self.a_cur.copy_(a_emb)
-        if c_emb.data_ptr() != self.c_cur.data_ptr():
-            self.c_cur.copy_(c_emb)
+        if a_emb.data_ptr() != a_cur.data_ptr():
+            a_cur.copy_(a_emb)
+        if c_emb.data_ptr() != c_cur.data_ptr():
+            c_cur.copy_(c_emb)
         if v.data_ptr() != self.v.data_ptr():
             self.v.copy_(v.reshape(self.N, self.P))
 
+    def step(self, forced_actions=None):
+        """eager tick"""
+        self.policy_step(forced_actions)
+        self.t += 1
+
     def value_step(self):
-        ag, d = self.agent, self.d
+        """bootstrap value after the last step (:807-825): only the critic's embedding of the last tick enters the history"""
+        ag, d, t, M = self.agent, self.d, self.t, self.M
         hops = []
         if d:
-            h = self.hist if self.hist_c is None else self.hist_c
-            self._shift(h, [self.c_cur])
-            hops = [h[k] for k in range(d)]
+            if self.quirk:   # [c_{t-1}] + the list as it stood at the last tick, (c_{t-2}, a_{t-2}, c_{t-3}, ..)
+                hops = ([self.ring[(t - 1) % M][1]] + self._hops(t - 1)[1])[:d]
+            else:
+                hops = self._hops(t)[1]
         v, hc, c_emb = ag.critic(self._obs(), hops, self.hc, 0, rollout=True)
         self.v.copy_(v.reshape(self.N, self.P))
 
     def replay_policy_step(self):
-        if self.graph is None:
-            self._capture()
-        self.graph.replay()
+        phase = self.t % self.M
+        g = self.graphs.get(phase)
+        if g is None:
+            g = self.graphs[phase] = self._capture()
+        g.replay()
+        self.t += 1
 
     def _capture(self):
-        """Records policy_step once.  The warm-up runs mutate the rollout state, so it is saved and restored."""
-        keep = [t.clone() for t in (self.ha, self.hc, self.hist, self.a_cur, self.c_cur, self.counter, self.a_n, self.logp, self.v)]
-        keep_c = self.hist_c.clone() if self.hist_c is not None else None
+        """Records the tick program of the current phase once.  The warm-up runs mutate the rollout state, so it is saved and
+        restored."""
+        live = (self.ha, self.hc, self.ring, self.counter, self.a_n, self.logp, self.v)
+        keep = [t.clone() for t in live]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -431,8 +457,6 @@ class _RolloutState:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):   # a background evaluator may launch on its own stream meanwhile
             self.policy_step()
-        for t, k in zip((self.ha, self.hc, self.hist, self.a_cur, self.c_cur, self.counter, self.a_n, self.logp, self.v), keep):
+        for t, k in zip(live, keep):
             t.copy_(k)
-        if keep_c is not None:
-            self.hist_c.copy_(keep_c)
-        self.graph = g
+        return g

@@ -312,11 +312,22 @@ def sequence_forward_pair(actor, critic, obs, hist_a, hist_c, batch, steps):
 
 
 def build_actor_critic(cfg, device):
-    """encoder -> actor -> critic, the construction order of MAPPO.__init__ (:582-616); encoder is shared."""
+    """encoder -> actor -> critic, the construction order of MAPPO.__init__ (:582-616); encoder is shared.
+    `algo.encoder: gnn_extractor` (ours; default `dhgn`) selects the older one-hop encoder instead (GnnEncoder below; reference
+    obstacle_differ_3hop/mappo_parallel.py:277-302: one instance per network, constructed actor first)."""
     sn = cfg.algo.use_spectral_norm
-    enc = DHGN(cfg.env.state_dim, cfg.algo.embedding_dim, sn, cfg.algo, device)
+    kind = str(cfg.algo.get("encoder", "dhgn")).lower()
+    if kind in ("gnn_extractor", "gnnextractor", "gnn"):
+        if int(cfg.algo.depth) != GnnEncoder.HISTORY:
+            raise ValueError(f"algo.encoder=gnn_extractor reads each network's own last {GnnEncoder.HISTORY} embeddings: set algo.depth={GnnEncoder.HISTORY}")
+        enc = GnnEncoder(cfg.env.state_dim, cfg.algo.embedding_dim, sn, cfg.algo)
+        enc_c = GnnEncoder(cfg.env.state_dim, cfg.algo.embedding_dim, sn, cfg.algo)
+    elif kind == "dhgn":
+        enc = enc_c = DHGN(cfg.env.state_dim, cfg.algo.embedding_dim, sn, cfg.algo, device)
+    else:
+        raise ValueError(f"algo.encoder={kind!r}: 'dhgn' or 'gnn_extractor'")
     actor = SharedActor(enc, cfg.algo.embedding_dim, cfg.env.action_dim, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
-    critic = SharedCritic(enc, cfg.algo.embedding_dim, 1, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
+    critic = SharedCritic(enc_c, cfg.algo.embedding_dim, 1, cfg.algo.num_layers, cfg.algo.rnn_hidden_dim, is_sn=sn)
     if not bool(cfg.algo.get("use_rnn", True)):
         if cfg.algo.embedding_dim != cfg.algo.rnn_hidden_dim:
             raise ValueError("algo.use_rnn=false feeds the embedding to the heads: embedding_dim must equal rnn_hidden_dim")
@@ -346,3 +357,57 @@ class GnnExtractor(nn.Module):
         h0_agg = torch.matmul(abar.unsqueeze(-2), h0).squeeze(-2)            # (*, A, O)
         comm_agg = torch.matmul(abar[..., :A], last_comm_embedding)          # the first A neighbours are the agents (:62-65)
         return self.bottleneck(torch.cat([h0_agg, comm_agg], dim=-1))
+
+
+class GnnEncoder(GnnExtractor):
+    """`algo.encoder: gnn_extractor` -- GnnExtractor as the `shared_net` of SharedActor / SharedCritic on the pursuit-evasion game
+    ("the obstacle_differ_3hop.GnnExtractor variant as an alternative encoder").  Same parameters and forward as the
+    block above (`one_hop.{0,2}`, `bottleneck.0`: the reference's checkpoints of that encoder load); what is OURS is the observation
+    contract, because the environment that fed the reference's 3-hop agent its `state (*, A, K, F)` / `adj (*, A, K)` tensors is not
+    in the reference tree (parity beyond the block is unpinned, tests/test_gnn_extractor.py):
+      entities of a row: the P defenders, the evader, the O padded boundary obstacles (K = P + 1 + O);
+      obs[i][j] = [state_j - state_i (4), one-hot(type of j) (3)];  adj = [p_adj | e_adj | o_adj] (the actor; the critic: ones,
+      obstacle_differ_3hop/mappo_parallel.py:193);  last_comm_embedding = this network's own last two embeddings [t-2 | t-1]
+      (:459-461, :526-527) -- MAPPO's history plumbing with algo.depth = 2 and a clean per-network history.
+    The per-pair two-layer MLP (P K (2 F E + 2 E^2) flops per row: 51 MFLOP at P = 8, K = 185 -- seven times the whole DHGN network)
+    runs in plain torch GEMMs, row-chunked; it is an alternative for small batches, not a benchmark path."""
+    HISTORY = 2
+    PAIR_FEATURES = 7
+    CHUNK_PAIRS = 1 << 21
+
+    def __init__(self, input_dim, embedding_dim, is_sn, algo_config):
+        super().__init__(self.PAIR_FEATURES, int(algo_config.get("gnn_middle_dim", embedding_dim)), embedding_dim, is_sn=bool(is_sn))
+        self.depth = self.HISTORY
+        self.input_dim, self.embedding_dim = input_dim, embedding_dim
+
+    def observation(self, p, e, o, adj_p, adj_e, adj_o, is_critic, q_div=1):
+        """-> obs (R, P, K, 7), adj (R, P, K)"""
+        R, P = p.shape[0], p.shape[1]
+        O = o.shape[1]
+        if adj_o.dtype == torch.int32:
+            adj_o = ops.unpack_adj_bits(adj_o, O)
+        oq = o if q_div == 1 else o.repeat_interleave(q_div, dim=0)
+        q = torch.cat([p, e.reshape(R, 1, -1), oq], dim=1)                                  # (R, K, 4)
+        idx = torch.arange(P + 1 + O, device=p.device)       # device-side construction: this runs inside captured tick programs
+        kind = torch.stack((idx < P, idx == P, idx > P), dim=-1).to(p.dtype)
+        rel = q[:, None, :, :] - p[:, :, None, :]                                           # (R, P, K, 4)
+        obs = torch.cat([rel, kind.expand(R, P, P + 1 + O, 3)], dim=-1)
+        adj = torch.cat([adj_p, adj_e, adj_o], dim=-1)
+        return obs, (torch.ones_like(adj) if is_critic else adj)
+
+    def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):
+        R, P = p.shape[0], p.shape[1]
+        K = P + 1 + o.shape[1]
+        last = torch.cat([hist[1], hist[0]], dim=-1).reshape(R, P, 2 * self.embedding_dim)  # hop k = the embedding of step t-1-k
+        step = max(q_div, (self.CHUNK_PAIRS // (P * K)) // q_div * q_div) if q_div > 1 else max(1, self.CHUNK_PAIRS // (P * K))
+        parts = []
+        for r0 in range(0, R, step):
+            r1 = min(R, r0 + step)
+            oc = o[r0 // q_div: (r1 + q_div - 1) // q_div] if q_div > 1 else o[r0:r1]
+            obs, adj = self.observation(p[r0:r1], e[r0:r1], oc, adj_p[r0:r1], adj_e[r0:r1], adj_o[r0:r1], is_critic, q_div)
+            parts.append(GnnExtractor.forward(self, obs, last[r0:r1], adj))
+        y = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y

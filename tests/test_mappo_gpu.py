@@ -330,3 +330,34 @@ def test_depth0_buffer_embeddings_are_zero_unless_recording_is_requested():
         assert bufs[1][k].abs().sum() > 0 and bufs[1][k][:, 0].abs().sum() > 0
     for k in ("a_n", "v_n", "a_logprob_n", "r", "p_state"):
         assert torch.equal(bufs[0][k], bufs[1][k]), k
+
+
+def test_gnn_extractor_encoder_trains_in_mappo():
+    """`algo.encoder: gnn_extractor`: rollout (per-network histories of the last two embeddings) + update + Adam
+    step through the alternative encoder; captured-graph rollout == eager rollout; both encoders and both GRUs receive gradients."""
+    from distributed_multi_agent_reinforcement_learning_amd.mappo import MAPPO
+    from distributed_multi_agent_reinforcement_learning_amd.model import GnnEncoder
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from tests.helpers import product_cfg
+    bufs = []
+    for use_graphs in (True, False):
+        cfg = product_cfg(4, 20, 20, T=12, depth=2, blocks=2, variance=4, **{"algo.encoder": "gnn_extractor", "runtime.use_graphs": use_graphs, "runtime.seed": 3})
+        torch.manual_seed(8)
+        agent = MAPPO(cfg, 8, 4, "Learner")
+        assert isinstance(agent.actor.shared_net, GnnEncoder) and agent.actor.shared_net is not agent.critic.shared_net
+        assert len(agent.ac_parameters) == len(list(agent.actor.parameters())) + len(list(agent.critic.parameters()))
+        env = Pursuit_Env(cfg, num_envs=8)
+        exp_r, rb, steps = agent.explore_env(env, 1)
+        assert steps == 8 * 12 and agent._rstate.hist_c is not None       # clean per-network histories
+        bufs.append({k: v.clone() for k, v in rb.buffer.items() if k != "o_state"})
+    for k in bufs[0]:
+        assert torch.equal(bufs[0][k], bufs[1][k]), k
+    emb = bufs[0]["actor_historical_embedding"]
+    assert emb.shape == (8, 12 + 2, 4, 128) and emb[:, 2:].abs().sum() > 0 and not emb[:, :2].any()
+    before = [p.detach().clone() for p in agent.ac_parameters]
+    with torch.enable_grad():
+        objC, objA, ag, cg = agent.train(rb, steps)
+    assert np.isfinite(objC) and np.isfinite(objA)
+    assert all(g is not None and np.isfinite(g).all() and np.any(g) for g in ag + cg)
+    agent.ac_optimizer.step()
+    assert all(not torch.equal(p.detach(), b) for p, b in zip(agent.ac_parameters, before))

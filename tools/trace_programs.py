@@ -27,10 +27,10 @@ def kernels_in_order(prof):
 print(f"== {name}: one eager rollout tick program ==")
 with torch.no_grad():
     for _ in range(2):
-        st.policy_step()
+        st.step()
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-        st.policy_step()
+        st.step()
         torch.cuda.synchronize()
 tot = 0.0
 for e in kernels_in_order(prof):
