@@ -154,7 +154,7 @@ def measure_compute_kernels(trainer, cfg):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         w, b = torch.randn(384, 128, device=dev) * 0.08, torch.zeros(384, device=dev)
         t = timeit(lambda: L.gru_seq_fwd(T, B, 128, ptr(gi), ptr(w), ptr(b), ptr(h0[0]), ptr(o), None, 0, st))
-        out["gru_seq_fwd"] = entry("k_gru_seq_fwd (recurrent GEMM h W_hh^T + gates, T steps in one launch)", 2.0 * T * B * 128 * 384, t,
+        out["gru_seq_fwd"] = entry("k_gru_seq_fwd2 (recurrent GEMM h W_hh^T + gates, T steps in one launch; no saved gates)", 2.0 * T * B * 128 * 384, t,
                                    rows=B, steps=T)
         Kr = mb * T * P  # rows of one mini-batch: the weight gradient of a GRU projection reduces over all of them
         ga = torch.randn(Kr, 384, device=dev); xa = torch.randn(Kr, 128, device=dev)

@@ -185,7 +185,10 @@ class MAPPO:
         self.last_adv, self.last_v_target = adv, v_target
         object_critics = object_actors = 0.0
         update_time = 0
-        self.ac_optimizer.zero_grad()
+        if getattr(self, "grad_bucket", None) is not None:
+            self.grad_bucket.zero()          # persistent flat gradient storage (trainer.GradBucket): zeroed, not dropped
+        else:
+            self.ac_optimizer.zero_grad()
         d = self.depth
         for n0 in range(0, N, self.mini_batch_size):  # BatchSampler(SequentialSampler, mini_batch_size, drop_last=False)
             n1 = min(n0 + self.mini_batch_size, N)

@@ -82,6 +82,32 @@ def set_flat_grads(params, flat):
         o += n
 
 
+class GradBucket:
+    """The gradients of `params` as views of ONE persistent flat fp32 tensor (ac_parameters order): autograd accumulates straight
+    into the bucket, the collective reduces the bucket in place and the optimiser reads the same memory -- no torch.cat before the
+    all-reduce and no per-parameter clone after it.  Parameters that receive no gradient (an unused GRU under algo.use_rnn: false)
+    contribute zeros, which is what the SUM over learners of `None` entries amounts to (main.py:121-126)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        self.attach()
+
+    def attach(self):
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[o:o + n].view_as(p)
+            o += n
+
+    def zero(self):
+        if any(p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4
+               for p in self.params):
+            self.attach()   # someone replaced a gradient tensor (e.g. a zero_grad(set_to_none=True)): re-attach the views
+        self.flat.zero_()
+
+
 def broadcast_weights_(modules, src=0):
     """initial weight sync from learner 0 (main.py:73-75)"""
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -137,6 +163,8 @@ class Trainer:
         torch.manual_seed(int(cfg.runtime.get("seed", 0)))
         self.agent = MAPPO(cfg, batch, self.mini_batch_size, "Learner")
         self.agent.sample_rank = self.rank  # disjoint action-sampling streams per rank (mappo.MAPPO.sample_rank)
+        self.bucket = GradBucket(self.agent.ac_parameters)   # .grad of every parameter lives in one flat tensor
+        self.agent.grad_bucket = self.bucket
         broadcast_weights_([self.agent.actor, self.agent.critic])
         self.total_steps = 0
         self.iteration = 0
@@ -154,8 +182,7 @@ class Trainer:
         for _ in range(int(cfg.algo.epochs)):
             with torch.enable_grad():
                 obj_c, obj_a, _, _ = agent.train(buffer, self.total_steps, return_grads=False)
-            flat = allreduce_sum_(flat_grads(agent.ac_parameters))
-            set_flat_grads(agent.ac_parameters, flat)
+            allreduce_sum_(self.bucket.flat)      # gradient SUM over ranks, in place in the bucket the optimiser reads
             agent.ac_optimizer.step()
             if cfg.algo.use_lr_decay:
                 agent.lr_decay(self.total_steps)

@@ -1,11 +1,11 @@
-"""rocprofv3 outputs of tools/profile_gru.py -> profiles/r02_gru_mfma_counters.json: per hand-written MFMA kernel the average
+"""rocprofv3 outputs of tools/profile_gru.py -> profiles/r03_gru_mfma_counters.json: per hand-written MFMA kernel the average
 duration (kernel trace), MFMA busy cycles, and MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE x #SIMDs) -- the
 derived-counter formula rocprofv3 lists for MfmaUtil -- next to the algorithmic fp32 rate against the 157.3 TFLOP/s peak.
   python tools/mfma_summary.py <dir>"""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
-KERNELS = {"k_gru_seq_fwd": 2.0 * 150 * 3280 * 128 * 384, "k_gru_seq_bwd": 2.0 * 150 * 3280 * 384 * 128, "k_gru_cell": 2.0 * 32768 * 128 * 768,
+KERNELS = {"k_gru_seq_fwd2": 2.0 * 150 * 3280 * 128 * 384, "k_gru_seq_bwd2": 2.0 * 150 * 3280 * 384 * 128, "k_gru_cell": 2.0 * 32768 * 128 * 768,
            "k_wgrad<3, 1>": 2.0 * 492000 * 384 * 128}
 cnt = {}
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -33,5 +33,5 @@ for k, fl in KERNELS.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         e["MfmaUtil_percent"] = round(100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 2)
     out["kernels"][k] = e
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_gru_mfma_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r03_gru_mfma_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

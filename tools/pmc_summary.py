@@ -17,8 +17,12 @@ d = sys.argv[1]
 us = float(sys.argv[sys.argv.index("--us-per-launch") + 1]) if "--us-per-launch" in sys.argv else None
 N = int(sys.argv[sys.argv.index("--num-envs") + 1]) if "--num-envs" in sys.argv else 4096
 layout = sys.argv[sys.argv.index("--layout") + 1] if "--layout" in sys.argv else "packed"
+passes = sys.argv[sys.argv.index("--passes") + 1].split(",") if "--passes" in sys.argv else None   # sub-directories of <dir> to read
 acc = {}
-for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+if passes:
+    files = [f for f in files if os.path.relpath(f, d).split(os.sep)[0] in passes]
+for f in files:
     for r in csv.DictReader(open(f)):
         if "k_tick<true, true, true, false" not in r["Kernel_Name"]:
             continue
