@@ -1056,9 +1056,16 @@ __device__ __forceinline__ size_t gru_gi_row(int b, int t, int T, int B, int gi_
 constexpr int GC_LD = 36;  // 32 contraction steps + 4 pad floats per (q-plane, row)
 __device__ __forceinline__ int gc_idx(int row, int k) { return ((k >> 5) * GRU_RB + row) * GC_LD + (k & 31); }
 
-__global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, const float *__restrict__ x, const float *__restrict__ hprev,
-                                                  const float *__restrict__ w_ih, const float *__restrict__ w_hh,
-                                                  const float *__restrict__ b_ih, const float *__restrict__ b_hh, float *__restrict__ hout) {
+// Several independent cells of one shape (the actor's and the critic's layer of the same depth) as ONE launch: blockIdx.y selects the
+// cell, the persistent workgroups are divided between them.  Every workgroup pays the weight prologue (393 KB from L2) once per
+// launch; two cells in one launch halve the prologues per tile and the launches per tick.
+struct GruCellNets { mo_gru_cell_net n[MO_GRU_MAX_NETS]; };
+
+__global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, GruCellNets nets) {
+    const mo_gru_cell_net &net = nets.n[blockIdx.y];
+    const float *__restrict__ x = net.x, *__restrict__ hprev = net.h_prev, *__restrict__ w_ih = net.w_ih, *__restrict__ w_hh = net.w_hh,
+                *__restrict__ b_ih = net.b_ih, *__restrict__ b_hh = net.b_hh;
+    float *__restrict__ hout = net.h_out;
     constexpr int TILE = 4 * GRU_RB * GC_LD;
     __shared__ __attribute__((aligned(16))) float xs[2][TILE], hs[2][TILE];
     __shared__ __attribute__((aligned(16))) float whn_s[8][TILE];  // W_hn B-operands of the 8 waves (64 KB), same layout as an A tile
@@ -2095,16 +2102,30 @@ int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, 
     return (int)hipGetLastError();
 }
 
-int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,
-                 const float *b_hh, float *h_out, void *stream) {
-    if (B < 1 || H != GRU_H || !x || !h_prev || !w_ih || !w_hh || !b_ih || !b_hh || !h_out) return MO_ERR_BAD_ARG;
-    if (((uintptr_t)x & 15) || ((uintptr_t)h_prev & 15)) return MO_ERR_BAD_ARG;
+int gru_cell_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, int32_t H, void *stream) {
+    if (n_nets < 1 || n_nets > MO_GRU_MAX_NETS || !nets || B < 1 || H != GRU_H) return MO_ERR_BAD_ARG;
+    GruCellNets a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < n_nets; k++) {
+        const mo_gru_cell_net &m = nets[k];
+        if (!m.x || !m.h_prev || !m.w_ih || !m.w_hh || !m.b_ih || !m.b_hh || !m.h_out) return MO_ERR_BAD_ARG;
+        if (((uintptr_t)m.x & 15) || ((uintptr_t)m.h_prev & 15) || ((uintptr_t)m.w_ih & 15) || ((uintptr_t)m.w_hh & 15)) return MO_ERR_BAD_ARG;
+        a.n[k] = m;
+    }
     const int nblk = (B + GRU_RB - 1) / GRU_RB;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const int grid = nblk < cus ? nblk : cus;
-    hipLaunchKernelGGL(k_gru_cell, dim3(grid), dim3(512), 0, (hipStream_t)stream, (int)B, nblk, x, h_prev, w_ih, w_hh, b_ih, b_hh, h_out);
+    int per = cus / n_nets;     // persistent workgroups per cell: one per CU in total
+    if (per < 1) per = 1;
+    const int grid = nblk < per ? nblk : per;
+    hipLaunchKernelGGL(k_gru_cell, dim3(grid, n_nets), dim3(512), 0, (hipStream_t)stream, (int)B, nblk, a);
     return (int)hipGetLastError();
+}
+
+int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,
+                 const float *b_hh, float *h_out, void *stream) {
+    const mo_gru_cell_net net{x, h_prev, w_ih, w_hh, b_ih, b_hh, h_out};
+    return gru_cell_fwd_multi(1, &net, B, H, stream);
 }
 
 int64_t gru_seq_save_elems(int32_t T, int32_t B) { return (int64_t)T * ((B + GRU_RB - 1) / GRU_RB) * 4 * 512 * 4; }

@@ -391,8 +391,15 @@ class _RolloutState:
             emb = ag.actor.shared_net.forward_pair(o["p_state"], o["e_state"], o["o_state"], o["p_adj"], o["e_adj"], o["o_adj_bits"],
                                                    hops_a, hops_c, o["o_kvalid"], 1, slot)
             a_emb, c_emb = emb[0], emb[1]
-            feat_a, ha = ag.actor._rollout_features(a_emb, self.ha, True)
-            feat_c, hc = ag.critic._rollout_features(c_emb, self.hc, True)
+            if ag.actor.use_rnn and ag.critic.use_rnn:
+                # the two GRU trunks layer by layer, actor's and critic's cell in one launch; hidden states updated in place
+                E = a_emb.shape[-1]
+                fa, fc = ops.gru_step_multi([a_emb.reshape(-1, E), c_emb.reshape(-1, E)], [self.ha, self.hc], [ag.actor.GRU, ag.critic.GRU])
+                feat_a, feat_c = fa.reshape(self.N, self.P, -1), fc.reshape(self.N, self.P, -1)
+                ha, hc = self.ha, self.hc
+            else:
+                feat_a, ha = ag.actor._rollout_features(a_emb, self.ha, True)
+                feat_c, hc = ag.critic._rollout_features(c_emb, self.hc, True)
             v = ag.critic.head(feat_c, out=self.v)            # the value lands in the static storage
             w_a = ag.actor.head_weight() if forced_actions is None else None
             feat_a = feat_a.contiguous()

@@ -211,6 +211,10 @@ int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float 
  */
 int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,
                  const float *b_hh, float *h_out, void *stream);
+/* Several independent cells of one shape (actor and critic) in ONE launch; records of HOST memory holding DEVICE pointers, meaning as
+ * in gru_cell_fwd.  The persistent workgroups (one per CU) are divided between the cells. */
+typedef struct mo_gru_cell_net { const float *x, *h_prev, *w_ih, *w_hh, *b_ih, *b_hh; float *h_out; } mo_gru_cell_net;
+int gru_cell_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, int32_t H, void *stream);
 
 /*
  * PPO clipped-surrogate policy loss and clipped value loss of one mini-batch with their gradients

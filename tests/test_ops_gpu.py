@@ -690,3 +690,21 @@ def test_gru_multi_equals_separate_calls(T, n, P, agents):
         res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs], [p.grad.clone() for m in mods for p in m.parameters()]))
     for a, b in zip(res[0][0] + res[0][1] + res[0][2], res[1][0] + res[1][1] + res[1][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B", [32768, 4096, 1030])
+def test_gru_step_multi_equals_separate_cells(B):
+    """ops.gru_step_multi: actor's and critic's rollout GRU step, the two cells of every layer in one launch, hidden states updated in
+    place -- bit-identical to ops.gru per module (the same kernel on the same tiles)."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(B)
+    mods = [torch.nn.GRU(128, 128, 2).cuda() for _ in range(2)]
+    xs = [torch.randn(B, 128, device="cuda") for _ in range(2)]
+    h0 = [torch.randn(2, B, 128, device="cuda") for _ in range(2)]
+    with torch.no_grad():
+        ref = [ops.gru(x.unsqueeze(0), h.clone(), m) for x, h, m in zip(xs, h0, mods)]
+        hs = [h.clone() for h in h0]
+        outs = ops.gru_step_multi(xs, hs, mods)
+    for k in range(2):
+        assert torch.equal(outs[k], ref[k][0][0]) and torch.equal(hs[k], ref[k][1])
+        assert outs[k].data_ptr() == hs[k][1].data_ptr()
