@@ -343,13 +343,14 @@ __global__ __launch_bounds__(256) void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDi
                             const float *__restrict__ b0, const float *__restrict__ q1, const void *__restrict__ adj1,
                             const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ q2,
                             const void *__restrict__ adj2, const int32_t *__restrict__ kvalid2, const float *__restrict__ W2,
-                            const float *__restrict__ b2, float *__restrict__ out, float *__restrict__ out_c, int c_valid,
+                            const float *__restrict__ b2, float *__restrict__ out, float *__restrict__ out_c, int c_valid, int c_rel2,
                             const float *__restrict__ Wp, int64_t wp_rs, const float *__restrict__ bp, float *__restrict__ pos_a,
                             float *__restrict__ pos_c, int64_t pos_ld) {
     const int E = d0.E;
     msgw_fwd_rows<PT, S01, S01, EV>(d0, p, q0, e0, adj0, kvalid2, W0, b0, out, out_c, false);
     msgw_fwd_rows<PT, S01, S01, EV>(d1, p, q1, e0, adj1, kvalid2, W1, b1, out + E, out_c ? out_c + E : nullptr, false);
-    msgw_fwd_rows<PT, false, AS2, EV>(d2, p, q2, e0, adj2, kvalid2, W2, b2, out + 2 * E, out_c ? out_c + 2 * E : nullptr, c_valid != 0);
+    // c_rel2 == 0 (the update): the critic's obstacle relation is left to the sorted all-ones kernel (k_msg_ones_sorted_fwd)
+    msgw_fwd_rows<PT, false, AS2, EV>(d2, p, q2, e0, adj2, kvalid2, W2, b2, out + 2 * E, (out_c && c_rel2) ? out_c + 2 * E : nullptr, c_valid != 0);
     if (pos_a != nullptr) {
         // the position part of DHGN's semantic layer, bp + Wp p_i (Wp = the first four input columns, :284-303), for the same rows:
         // the addend the embedding part of that layer accumulates into; identical for actor and critic, written to both
@@ -378,10 +379,15 @@ __global__ __launch_bounds__(256) void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDi
 // k_msg_agg_bwd_reduce).  dW[:, k<4] = sum_i G_i p_i[k] - sum_j H_j q_j[k] with G_i = sum_j g_ij, H_j = sum_i g_ij,
 // g_ij = [z_ij > 0] abar_ij gout_i ; dW[:, 4+k] = sum_i G_i (p_i - e)[k] ; db = sum_i G_i.  For MO_ADJ_BITS the
 // neighbour-coordinate term is summed edge by edge instead of column by column (fp32 reassociation only).
-template <int PT, bool QS, bool AS, int EV>
+template <int PT, bool QS, bool AS, int EV, bool PAIR>
 __global__ __launch_bounds__(256) void k_msgw_bwd(MsgDims d, const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
                            const void *__restrict__ adj, const int32_t *__restrict__ kvalid, const float *__restrict__ W,
-                           const float *__restrict__ b, const float *__restrict__ gout, float *__restrict__ partials) {
+                           const float *__restrict__ b, const float *__restrict__ gout, const float *__restrict__ gout_c,
+                           float *__restrict__ partials) {
+    // PAIR (a separate instantiation: the second gradient costs 30 registers, which the single-network kernels must not pay),
+    // gout_c != nullptr (MO_ADJ_TENSOR only): the SAME relation of the critic (adjacency = ones over all K neighbours, shared weights)
+    // in the same pass -- the two networks' messages share z_ij, so g_ij = [z_ij > 0] (abar_ij gout_i + gout_c_i / K) and the sum of
+    // both weight gradients lands in one set of partials
     const int P = d.P, K = d.K, fs = blockDim.x, f = threadIdx.x;
     FV<EV> w[8], gw[8], bias, gb(0.f);
     msgw_weights<EV>(d, W, b, f, w, bias, fs);
@@ -390,15 +396,22 @@ __global__ __launch_bounds__(256) void k_msgw_bwd(MsgDims d, const float *__rest
     const int r0 = blockIdx.x * d.rpb, r1 = min(d.R, r0 + d.rpb);
     const bool use_kv = d.adj_mode == MO_ADJ_VALID;
     MsgRow m = msgw_load<QS, AS>(d, r0 < r1 ? r0 : 0, p, q, e, adj, kvalid, use_kv);
-    FV<EV> go[PT];
+    FV<EV> go[PT], goc[PT];
+    const float inv_k = 1.f / fmaxf((float)K, 1e-12f);
 #pragma unroll
-    for (int i = 0; i < PT; i++) go[i] = (i < P && r0 < r1) ? fv_load<EV>(gout + ((size_t)r0 * P + i) * d.o_is, f, fs) : FV<EV>(0.f);
+    for (int i = 0; i < PT; i++) {
+        go[i] = (i < P && r0 < r1) ? fv_load<EV>(gout + ((size_t)r0 * P + i) * d.o_is, f, fs) : FV<EV>(0.f);
+        goc[i] = (PAIR && i < P && r0 < r1) ? fv_load<EV>(gout_c + ((size_t)r0 * P + i) * d.o_is, f, fs) * inv_k : FV<EV>(0.f);
+    }
     for (int r = r0; r < r1; r++) {
         const int rn = r + 1 < r1 ? r + 1 : r;
         const MsgRow nxt = msgw_load<QS, AS>(d, rn, p, q, e, adj, kvalid, use_kv);
-        FV<EV> gon[PT];
+        FV<EV> gon[PT], gocn[PT];
 #pragma unroll
-        for (int i = 0; i < PT; i++) gon[i] = i < P ? fv_load<EV>(gout + ((size_t)rn * P + i) * d.o_is, f, fs) : FV<EV>(0.f);
+        for (int i = 0; i < PT; i++) {
+            gon[i] = i < P ? fv_load<EV>(gout + ((size_t)rn * P + i) * d.o_is, f, fs) : FV<EV>(0.f);
+            gocn[i] = (PAIR && i < P) ? fv_load<EV>(gout_c + ((size_t)rn * P + i) * d.o_is, f, fs) * inv_k : FV<EV>(0.f);
+        }
         const float4 *__restrict__ q4 = (const float4 *)(q + (size_t)(r / d.q_div) * d.q_rs);
         FV<EV> c[PT], G[PT];
         msgw_center<PT, EV>(d, m, w, bias, c);
@@ -450,8 +463,8 @@ __global__ __launch_bounds__(256) void k_msgw_bwd(MsgDims d, const float *__rest
                 uint64_t cm = 0ull;
                 if (AS) {
                     cm = (k.nz >> j) & k.col;
-                    if (cm == 0ull) continue;
-                } else {
+                    if (cm == 0ull && !PAIR) continue;
+                } else if (!PAIR) {
                     bool any = false;
                     for (int i = 0; i < P; i++) any |= ar[i * K + j] != 0.f;
                     if (!any) continue;
@@ -464,13 +477,12 @@ __global__ __launch_bounds__(256) void k_msgw_bwd(MsgDims d, const float *__rest
                     if (i < P) {
                         float aij;
                         if (AS) {
-                            if (!((cm >> (i * K)) & 1ull)) continue;
-                            aij = k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, i * K + j));
+                            aij = ((cm >> (i * K)) & 1ull) ? (k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, i * K + j))) : 0.f;
                         } else {
                             aij = ar[i * K + j];
-                            if (aij == 0.f) continue;
                         }
-                        const FV<EV> g = fv_pos(c[i] - dj, gi[i] * aij);
+                        if (aij == 0.f && !PAIR) continue;
+                        const FV<EV> g = fv_pos(c[i] - dj, PAIR ? fv_fma(gi[i], aij, goc[i]) : gi[i] * aij);   // actor: abar_ij gout_i; critic: gout_c_i / K
                         G[i] = G[i] + g;
                         hj = hj + g;
                     }
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(256) void k_msgw_bwd(MsgDims d, const float *__rest
         gw[0] = gw[0] - hq0; gw[1] = gw[1] - hq1; gw[2] = gw[2] - hq2; gw[3] = gw[3] - hq3;
         m = nxt;
 #pragma unroll
-        for (int i = 0; i < PT; i++) go[i] = gon[i];
+        for (int i = 0; i < PT; i++) { go[i] = gon[i]; if (PAIR) goc[i] = gocn[i]; }
     }
     float *dst = partials + (size_t)blockIdx.x * (d.din + 1) * d.E;
     for (int k = 0; k < d.din; k++) fv_store<EV>(dst + k * d.E, f, fs, gw[k]);
@@ -1860,7 +1872,7 @@ int wgrad_split(int M, int N, int *am, int *bn) {  // tile shape and number of K
 
 int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int64_t p_rs, const int32_t *kvalid2, float *out, float *out_c,
                  int c_valid, int64_t out_stride, void *stream, bool pair, const float *Wp = nullptr, int64_t wp_rs = 0, const float *bp = nullptr,
-                 float *pos_a = nullptr, float *pos_c = nullptr, int64_t pos_ld = 0) {
+                 float *pos_a = nullptr, float *pos_c = nullptr, int64_t pos_ld = 0, int c_rel2 = 1) {
     MsgDims d[3];
     int grid = 1;
     for (int r = 0; r < 3; r++) {
@@ -1877,7 +1889,7 @@ int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int
 #define MSGW3_LAUNCH1(PT, S01, AS2, EV)                                                                                                     \
     hipLaunchKernelGGL((k_msgw3_fwd<PT, S01, AS2, EV>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d[0], d[1], d[2], p, rel[0].q,       \
                        rel[0].e, rel[0].adj, rel[0].W, rel[0].b, rel[1].q, rel[1].adj, rel[1].W, rel[1].b, rel[2].q, rel[2].adj, kvalid2,      \
-                       rel[2].W, rel[2].b, out, out_c, c_valid, Wp, wp_rs, bp, pos_a, pos_c, pos_ld ? pos_ld : (int64_t)E)
+                       rel[2].W, rel[2].b, out, out_c, c_valid, c_rel2, Wp, wp_rs, bp, pos_a, pos_c, pos_ld ? pos_ld : (int64_t)E)
 #define MSGW3_LAUNCH(PT, S01, AS2) do { if (ev2) MSGW3_LAUNCH1(PT, S01, AS2, 2); else MSGW3_LAUNCH1(PT, S01, AS2, 1); } while (0)
 #define MSGW3_PT(PT) { if (s01 && as2) MSGW3_LAUNCH(PT, true, true); else if (s01) MSGW3_LAUNCH(PT, true, false); else if (as2) MSGW3_LAUNCH(PT, false, true); else MSGW3_LAUNCH(PT, false, false); }
     if (P <= 8) MSGW3_PT(8) else MSGW3_PT(16)
@@ -1927,6 +1939,15 @@ int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t 
     return launch_msgw3(rel, R, P, E, p, p_rs, o_kvalid, out_actor, out_critic, o_kvalid != nullptr, out_stride, stream, true);
 }
 
+int dhgn_msg_agg3_pair01_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_rs, float *out_actor,
+                             float *out_critic, int64_t out_stride, void *stream) {
+    if (!rel || !p || !out_actor || !out_critic || R < 0) return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    for (int r = 0; r < 3; r++)
+        if (rel[r].adj_mode != MO_ADJ_TENSOR && rel[r].adj_mode != MO_ADJ_BITS) return MO_ERR_BAD_ARG;  // the actor's adjacency
+    return launch_msgw3(rel, R, P, E, p, p_rs, nullptr, out_actor, out_critic, 0, out_stride, stream, true, nullptr, 0, nullptr, nullptr, nullptr, 0, 0);
+}
+
 int dhgn_msg_agg3_pair_pos_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_rs, const int32_t *o_kvalid,
                                float *out_actor, float *out_critic, int64_t out_stride, const float *Wp, int64_t wp_row_stride, const float *bp,
                                float *pos_actor, float *pos_critic, int64_t pos_stride, void *stream) {
@@ -1940,29 +1961,49 @@ int dhgn_msg_agg3_pair_pos_fwd(const mo_msg_rel *rel, int32_t R, int32_t P, int3
 
 int64_t dhgn_msg_agg_bwd_workspace(int32_t E, int32_t din) { return (int64_t)BWD_BLOCKS * (din + 1) * E * sizeof(float); }
 
-int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
-                     int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const void *adj, int64_t adj_rs, int32_t adj_mode,
-                     const int32_t *kvalid, const float *W, const float *b, const float *gout, int64_t gout_stride, float *dW, float *db,
-                     void *workspace, void *stream) {
+static int msg_agg_bwd_launch(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
+                              int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const void *adj, int64_t adj_rs, int32_t adj_mode,
+                              const int32_t *kvalid, const float *W, const float *b, const float *gout, const float *gout_c, int64_t gout_stride,
+                              float *dW, float *db, void *workspace, void *stream) {
     int rc = check_msg(R, P, K, E, din, q_div, adj_mode, adj, kvalid, e);
     if (rc) return rc;
     if (!workspace || !gout || !dW || !db) return MO_ERR_BAD_ARG;
     if ((q_rs & 3) || gout_stride < E) return MO_ERR_BAD_ARG;
+    if (gout_c && adj_mode != MO_ADJ_TENSOR) return MO_ERR_BAD_ARG;
     int grid;
     const MsgDims d = msg_dims(R, P, K, E, din, q_div, adj_mode, p_rs, q_rs, e_rs, adj_rs, gout_stride, BWD_BLOCKS, &grid);
     const bool qs = msg_q_small(K), as = msg_adj_small(P, K, adj_mode), ev2 = (E % 128) == 0;
-#define MSGW_BWD1(PT, QS, AS, EV) \
-    hipLaunchKernelGGL((k_msgw_bwd<PT, QS, AS, EV>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d, p, q, e, adj, kvalid, W, b, gout, (float *)workspace)
+#define MSGW_BWD2(PT, QS, AS, EV, PAIR) \
+    hipLaunchKernelGGL((k_msgw_bwd<PT, QS, AS, EV, PAIR>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d, p, q, e, adj, kvalid, W, b, gout, gout_c, (float *)workspace)
+#define MSGW_BWD1(PT, QS, AS, EV) do { if (gout_c) MSGW_BWD2(PT, QS, AS, EV, true); else MSGW_BWD2(PT, QS, AS, EV, false); } while (0)
 #define MSGW_BWD(PT, QS, AS) do { if (ev2) MSGW_BWD1(PT, QS, AS, 2); else MSGW_BWD1(PT, QS, AS, 1); } while (0)
 #define MSGW_BWD_PT(PT) { if (qs && as) MSGW_BWD(PT, true, true); else if (qs) MSGW_BWD(PT, true, false); else if (as) MSGW_BWD(PT, false, true); else MSGW_BWD(PT, false, false); }
     if (P <= 8) MSGW_BWD_PT(8) else MSGW_BWD_PT(16)
 #undef MSGW_BWD_PT
 #undef MSGW_BWD
 #undef MSGW_BWD1
+#undef MSGW_BWD2
     const int tot = (din + 1) * E;
     hipLaunchKernelGGL(k_msg_agg_bwd_reduce, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, grid, E, din,
                        (const float *)workspace, dW, db);
     return (int)hipGetLastError();
+}
+
+int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
+                     int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const void *adj, int64_t adj_rs, int32_t adj_mode,
+                     const int32_t *kvalid, const float *W, const float *b, const float *gout, int64_t gout_stride, float *dW, float *db,
+                     void *workspace, void *stream) {
+    return msg_agg_bwd_launch(R, P, K, E, din, p, p_rs, q, q_rs, q_div, e, e_rs, adj, adj_rs, adj_mode, kvalid, W, b, gout, nullptr, gout_stride, dW, db,
+                              workspace, stream);
+}
+
+int dhgn_msg_agg_bwd_pair(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
+                          int64_t q_rs, int32_t q_div, const float *e, int64_t e_rs, const float *adj, int64_t adj_rs, const float *W,
+                          const float *b, const float *gout_actor, const float *gout_critic, int64_t gout_stride, float *dW, float *db,
+                          void *workspace, void *stream) {
+    if (!gout_critic) return MO_ERR_BAD_ARG;
+    return msg_agg_bwd_launch(R, P, K, E, din, p, p_rs, q, q_rs, q_div, e, e_rs, adj, adj_rs, MO_ADJ_TENSOR, nullptr, W, b, gout_actor, gout_critic,
+                              gout_stride, dW, db, workspace, stream);
 }
 
 int dhgn_msg_agg_ones_sorted_ok(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, int32_t q_div) {

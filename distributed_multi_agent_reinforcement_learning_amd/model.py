@@ -73,11 +73,15 @@ class DHGN(nn.Module):
         """p (R,P,4), e (R,1,4), o (R/q_div,O,4), adj_* (R,P,{P,1,O}) (adj_o may be bit-packed int32 rows) -> h0 (R,P,E).
         is_critic: adjacency := ones (AttributeDataset, :64-65); in a batched rollout the obstacle relation uses ones
         over the first o_kvalid[row] (real) obstacles, in training over all padded slots."""
-        R, P = p.shape[0], p.shape[1]
-        E, ind = self.embedding_dim, self.input_dim
         M = self.MSG_layers
         m3 = ops.msg_agg3(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
                           is_critic, o_kvalid, q_div)                                  # (R, P, 3, E)
+        return self._after_messages(p, m3, out)
+
+    def _after_messages(self, p, m3, out=None):
+        """AGG_vertex_0 on the three relation aggregates, then the semantic layer (:278-303)"""
+        R, P = p.shape[0], p.shape[1]
+        E, ind = self.embedding_dim, self.input_dim
         agg0 = self.AGG_layers["AGG_vertex_0"]
         emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)                       # one GEMM (+relu epilogue) for the three relations
         # semantic_layer([p, emb0, emb1, emb2]) without materialising the concatenation (:284-303)
@@ -91,6 +95,14 @@ class DHGN(nn.Module):
         else:
             h0 = ops.linear(e2, Ws[:, ind:], ops.linear_skinny(p2, Ws[:, :ind], self.semantic_layer.bias), consume_addend=True)
         return h0.reshape(R, P, E)
+
+    def encoder_pair_train(self, p, e, o, adj_p, adj_e, adj_o, q_div=1):
+        """the update's encoder of actor and critic together -> (h0_actor, h0_critic): one message pass for both networks
+        (ops.msg_agg3_pair_train), then the layers per network; same numbers as encoder(.., False) and encoder(.., True)."""
+        M = self.MSG_layers
+        m3a, m3c = ops.msg_agg3_pair_train(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
+                                           q_div)
+        return self._after_messages(p, m3a), self._after_messages(p, m3c)
 
     # -- fixed-depth recursive aggregation over neighbours' historical embeddings (:204-233) --------------
     def fcra(self, h0, hist, adj_p, is_critic, out=None):
@@ -294,10 +306,15 @@ def sequence_forward_pair(actor, critic, obs, hist_a, hist_c, batch, steps):
     """SharedActor.forward(mode 1) and SharedCritic.forward(mode 1) of one mini-batch together (DHGN/mappo_parallel.py:426-437,
     :503-520): the two encoders as before, then the two GRUs layer by layer with actor and critic in ONE persistent launch each way
     (ops.gru_multi) -- same numbers as the two module calls.  -> (prob (batch, steps, P, A), values (batch, steps, P, 1))."""
-    emb_a = actor.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_a, False, None,
-                             obs.get("q_div", 1), None)
-    emb_c = critic.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_c, True, None,
-                              obs.get("q_div", 1), None)
+    enc, q_div = actor.shared_net, obs.get("q_div", 1)
+    if (enc is critic.shared_net and isinstance(enc, DHGN) and obs["p_adj"].dtype == torch.float32
+            and ops.msg_agg3_pair_train_ok(obs["p_state"], obs["o_state"], enc.MSG_layers[2].weight, q_div)):
+        # shared DHGN: one message pass for both networks, forward and backward
+        h0a, h0c = enc.encoder_pair_train(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), q_div)
+        emb_a, emb_c = enc.fcra(h0a, hist_a, obs["p_adj"], False), enc.fcra(h0c, hist_c, obs["p_adj"], True)
+    else:
+        emb_a = actor.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_a, False, None, q_div, None)
+        emb_c = critic.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_c, True, None, q_div, None)
     P = emb_a.shape[1]
     if not (actor.use_rnn and critic.use_rnn):
         feat_a, feat_c = actor._sequence_features(emb_a, batch, steps), critic._sequence_features(emb_c, batch, steps)

@@ -38,6 +38,8 @@ def load_library():
         L.dhgn_msg_agg_bwd.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.dhgn_msg_agg3_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, i64, vp]
         L.dhgn_msg_agg3_pair_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp]
+        L.dhgn_msg_agg3_pair01_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, i64, vp]
+        L.dhgn_msg_agg_bwd_pair.argtypes = [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         L.dhgn_msg_agg3_pair_pos_fwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp]
         L.spectral_norm_weight.argtypes = [i32, i32, vp, vp, vp, f32, i32, vp, vp]
         L.dhgn_msg_agg_bwd_workspace.argtypes = [i32, i32]
@@ -374,6 +376,79 @@ class _MsgAgg3(torch.autograd.Function):
             _msg_call("bwd", L, p, q, ee, adj, kv, W, b, m, qd, slot(r), 3 * E, (_ptr(dW), _ptr(db), _ptr(ws)))
             grads += [dW, db]
         return (None,) * 7 + tuple(grads) + (None, None, None)
+
+
+class _MsgAgg3Pair(torch.autograd.Function):
+    """The update's message pass of ACTOR and CRITIC together (they hold the same DHGN instance, DHGN/mappo_parallel.py:582-616: same
+    MSG weights, same p / e / o rows, the observed adjacency vs ones): -> (m3_actor, m3_critic), each (R, P, 3, E).
+    Forward: one launch for the actor's three relations plus the critic's relations 0 and 1 (the messages are computed once); the
+    critic's obstacle relation (ones over all padded slots in training) is the sorted all-ones kernel.  Backward: relations
+    0 and 1 are ONE pass each for both networks (dhgn_msg_agg_bwd_pair: the two gradients share the ReLU mask and sum into one dW),
+    relation 2 the actor's bit-walk kernel plus the sorted kernel.  The numbers are those of two _MsgAgg3 nodes."""
+
+    @staticmethod
+    def forward(ctx, p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, q_div):
+        L = load_library()
+        _need_gpu(p, "dhgn_msg_agg")
+        R, P = p.shape[0], p.shape[1]
+        E, K = W0.shape[0], o.shape[1]
+        ws = [t.detach().contiguous() for t in (W0, b0, W1, b1, W2, b2)]
+        e2 = e.reshape(R, 4)
+        out_a = torch.empty((R, P, 3, E), dtype=torch.float32, device=p.device)
+        out_c = torch.empty((R, P, 3, E), dtype=torch.float32, device=p.device)
+        mode_o = ADJ_BITS if adj_o.dtype == torch.int32 else ADJ_TENSOR
+        arr = _msg3_rels(p, ((p, e2, adj_p, None, ws[0], ws[1], ADJ_TENSOR, 1), (e, None, adj_e, None, ws[2], ws[3], ADJ_TENSOR, 1),
+                             (o, None, adj_o, None, ws[4], ws[5], mode_o, q_div)))
+        _check(L.dhgn_msg_agg3_pair01_fwd(C.cast(arr, C.c_void_p), R, P, E, _ptr(p), p.stride(0), _ptr(out_a), _ptr(out_c), 3 * E, _stream()),
+               "dhgn_msg_agg3_pair01_fwd")
+        need = any(ctx.needs_input_grad)
+        save_m = torch.empty((R, P, E), dtype=torch.uint8, device=p.device) if need else None
+        qtab = torch.empty((R // q_div, E, 4, K + 1), dtype=torch.float32, device=p.device) if need else None
+        _check(L.dhgn_msg_agg_ones_sorted_fwd(R, P, K, E, _ptr(p), p.stride(0), _ptr(o), o.stride(0), q_div, _ptr(ws[4]), _ptr(ws[5]),
+                                              C.c_void_p(out_c.data_ptr() + 4 * 2 * E), 3 * E, _ptr(save_m), _ptr(qtab), _stream()),
+               "dhgn_msg_agg_ones_sorted_fwd")
+        ctx.save_for_backward(p, e, o, adj_p, adj_e, adj_o, save_m, qtab, *ws)
+        ctx.meta = (mode_o, q_div)
+        return out_a, out_c
+
+    @staticmethod
+    def backward(ctx, ga, gc):
+        L = load_library()
+        p, e, o, adj_p, adj_e, adj_o, save_m, qtab, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
+        mode_o, q_div = ctx.meta
+        R, P = p.shape[0], p.shape[1]
+        E = W0.shape[0]
+        ga, gc = ga.contiguous(), gc.contiguous()
+        slot = lambda g, r: C.c_void_p(g.data_ptr() + 4 * r * E)
+        grads = []
+        for r, (q, ee, adj, W, b) in enumerate(((p, e.reshape(R, 4), adj_p, W0, b0), (e, None, adj_e, W1, b1))):
+            K, din = q.shape[1], W.shape[1]
+            dW, db = torch.empty_like(W), torch.empty_like(b)
+            ws = _workspace(p.device, E, din)
+            assert adj.shape == (R, P, K) and adj.dtype == torch.float32 and _rows_ok(adj) and _rows_ok(q) and q.shape[0] == R
+            _check(L.dhgn_msg_agg_bwd_pair(R, P, K, E, din, _ptr(p), p.stride(0), _ptr(q), q.stride(0), 1, _ptr(ee), ee.stride(0) if ee is not None else 0,
+                                           _ptr(adj), adj.stride(0), _ptr(W), _ptr(b), slot(ga, r), slot(gc, r), 3 * E, _ptr(dW), _ptr(db), _ptr(ws),
+                                           _stream()), "dhgn_msg_agg_bwd_pair")
+            grads += [dW, db]
+        # the obstacle relation: actor (bit-packed / float adjacency) and critic (sorted all-ones), summed
+        dWa, dba = torch.empty_like(W2), torch.empty_like(b2)
+        _msg_call("bwd", L, p, o, None, adj_o, None, W2, b2, mode_o, q_div, slot(ga, 2), 3 * E, (_ptr(dWa), _ptr(dba), _ptr(_workspace(p.device, E, 4))))
+        dWc, dbc = torch.empty_like(W2), torch.empty_like(b2)
+        part = torch.empty((R // q_div) * 5 * E, dtype=torch.float32, device=p.device)
+        _check(L.dhgn_msg_agg_ones_sorted_bwd(R, P, o.shape[1], E, _ptr(p), p.stride(0), q_div, slot(gc, 2), 3 * E, _ptr(save_m), _ptr(qtab),
+                                              _ptr(dWc), _ptr(dbc), _ptr(part), _stream()), "dhgn_msg_agg_ones_sorted_bwd")
+        grads += [dWa + dWc, dba + dbc]
+        return (None,) * 6 + tuple(grads) + (None,)
+
+
+def msg_agg3_pair_train_ok(p, o, W2, q_div):
+    """shapes the paired update path covers (the critic's obstacle relation must take the sorted all-ones kernels)"""
+    return p.is_cuda and _sorted_ones_ok(load_library(), p, o, W2, ADJ_ONES, q_div)
+
+
+def msg_agg3_pair_train(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, q_div=1):
+    """-> (m3_actor, m3_critic) with autograd: msg_agg3(.., False) and msg_agg3(.., True) of one mini-batch from shared passes"""
+    return _MsgAgg3Pair.apply(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, q_div)
 
 
 def msg_agg3(p, e, o, adj_p, adj_e, adj_o, W0, b0, W1, b1, W2, b2, is_critic, o_kvalid=None, q_div=1):

@@ -68,6 +68,18 @@ int dhgn_msg_agg3_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int
 int dhgn_msg_agg3_pair_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_row_stride,
                            const int32_t *o_kvalid, float *out_actor, float *out_critic, int64_t out_stride, void *stream);
 
+/* The update's form of the paired launch: the actor's three relations and the critic's relations 0 and 1 (ones adjacency); slot 2
+ * of out_critic is NOT written -- in training the critic's obstacle relation averages over all K padded slots and is
+ * left to dhgn_msg_agg_ones_sorted_fwd. */
+int dhgn_msg_agg3_pair01_fwd(const mo_msg_rel *rel /* [3] */, int32_t R, int32_t P, int32_t E, const float *p, int64_t p_row_stride,
+                             float *out_actor, float *out_critic, int64_t out_stride, void *stream);
+/* Backward of ONE relation for actor and critic together (shared weights W, b: DHGN/mappo_parallel.py:582-616): the actor's
+ * gradient under the float adjacency adj [R][P][K] and the critic's under ones over all K neighbours, summed into dW / db in one
+ * pass over the messages (g_ij = [z_ij > 0] (abar_ij gout_actor_i + gout_critic_i / K)).  Arguments as dhgn_msg_agg_bwd. */
+int dhgn_msg_agg_bwd_pair(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_row_stride, const float *q,
+                          int64_t q_row_stride, int32_t q_div, const float *e, int64_t e_row_stride, const float *adj, int64_t adj_row_stride,
+                          const float *W, const float *b, const float *gout_actor, const float *gout_critic, int64_t gout_stride, float *dW,
+                          float *db, void *workspace, void *stream);
 /* The same launch, which also writes the position part of DHGN's semantic layer for these rows, pos[r][i][:] = bp + Wp p[r][i]
  * (Wp [E][4]: the first four input columns of semantic_layer.weight, wp_row_stride elements between its rows; mappo_parallel.py:
  * 284-303) -- the addend the embedding part of that layer accumulates into; the same numbers for both networks, written to

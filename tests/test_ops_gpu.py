@@ -464,6 +464,41 @@ def test_actor_critic_pair_launch_equals_two_launches(P, K, q_div, valid):
                 assert torch.equal(pair[1], critic)
 
 
+@pytest.mark.parametrize("P,K,T,packed", [(8, 176, 30, True), (4, 176, 12, True), (8, 40, 9, False), (15, 176, 10, True)])
+def test_actor_critic_pair_training_form_equals_two_autograd_nodes(P, K, T, packed):
+    """The update's paired message pass (ops.msg_agg3_pair_train: one forward launch for the actor's three relations + the critic's
+    relations 0 and 1, the sorted all-ones kernels for the critic's obstacle relation, relations 0 and 1 of BOTH networks in one backward
+    pass each) against two msg_agg3 autograd nodes: outputs bit-identical, the summed weight gradients equal to fp32 reassociation."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(5 + P + K)
+    n, E = 6, 128
+    R = n * T
+    p = (torch.randn(R, P, 4) * 10 + 20).cuda(); e = (torch.randn(R, 1, 4) * 10 + 20).cuda()
+    o = torch.zeros(n, K, 4); o[:, :, :2] = torch.randint(0, 40, (n, K, 2)).float(); o = o.cuda()
+    adj_p = (torch.rand(R, P, P) < 0.5).float().cuda(); adj_e = (torch.rand(R, P, 1) < 0.5).float().cuda()
+    adj_o = (torch.rand(R, P, K) < 0.1).float().cuda()
+    adj_p[1] = 0.0; adj_e[2] = 0.0; adj_o[3] = 0.0
+    ao = ops.pack_adj_bits(adj_o) if packed else adj_o
+    ga, gc = torch.randn(R, P, 3, E, device="cuda"), torch.randn(R, P, 3, E, device="cuda")
+
+    def params():
+        torch.manual_seed(99)
+        Ws = [(torch.randn(E, d) * 0.3).cuda().requires_grad_(True) for d in (8, 4, 4)]
+        bs = [(torch.randn(E) * 0.1).cuda().requires_grad_(True) for _ in range(3)]
+        return (Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2])
+    assert ops.msg_agg3_pair_train_ok(p, o, params()[4], T)
+    wb = params()
+    ma, mc = ops.msg_agg3_pair_train(p, e, o, adj_p, adj_e, ao, *wb, T)
+    ((ma * ga).sum() + (mc * gc).sum()).backward()
+    wr = params()
+    ra = ops.msg_agg3(p, e, o, adj_p, adj_e, ao, *wr, False, None, T)
+    rc = ops.msg_agg3(p, e, o, adj_p, adj_e, ao, *wr, True, None, T)
+    ((ra * ga).sum() + (rc * gc).sum()).backward()
+    assert torch.equal(ma, ra) and torch.equal(mc, rc)
+    for a, b in zip(wb, wr):
+        assert torch.allclose(a.grad, b.grad, rtol=2e-4, atol=2e-4 * float(b.grad.abs().max())), (a.shape, (a.grad - b.grad).abs().max())
+
+
 @pytest.mark.parametrize("A,H", [(1, 128), (9, 128), (16, 1000)])
 def test_spectral_norm_weight_matches_torch_hook(A, H):
     """spectral_norm_weight (one launch) against torch.nn.utils.spectral_norm's hook on the CPU in float64: the same u, v
