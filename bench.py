@@ -317,6 +317,8 @@ def run_config(name, args, with_roofline):
         ov["runtime.num_envs"] = args.num_envs
     if args.max_steps:
         ov["env.max_steps"] = args.max_steps
+    if args.update_group is not None:
+        ov["runtime.update_group"] = args.update_group
     cfg = baseline_config(name, **ov)
     if args.scaling == "strong":   # fixed total: the job's environments are divided over the ranks (BASELINE configs 4 / 5 state totals)
         total = int(args.total_envs or cfg.runtime.num_envs)
@@ -353,7 +355,8 @@ def run_config(name, args, with_roofline):
                breakdown_ms={"rollout_incl_reset": round(rollout_ms, 1), "gae_ppo_update_allreduce_adam": round(update_ms, 1)},
                workload=f"{name}: pursuit_evasion_game {P} defenders, {W}x{H} map, {N} envs/GPU, T={T}, DHGN depth {cfg.algo.depth} + "
                         f"2-layer GRU actor/critic, rollout + PPO update",
-               envs_per_gpu=N, episode_steps=T, mini_batch_size=tr.mini_batch_size, backend=(dist.get_backend() if world > 1 else None))
+               envs_per_gpu=N, episode_steps=T, mini_batch_size=tr.mini_batch_size, backend=(dist.get_backend() if world > 1 else None),
+               update_group=tr.agent.update_group, hbm_peak_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
     # GEMM-shaped algorithmic work of one iteration (SURVEY 8d F_net without the message terms, which the kernels do not execute as
     # flops): per network and env-step; the rollout runs each network forward once, every epoch of the update forward + backward (3x)
     E_, H_, A_, d_ = cfg.algo.embedding_dim, cfg.algo.rnn_hidden_dim, cfg.env.action_dim, cfg.algo.depth
@@ -418,6 +421,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
     ap.add_argument("--num-envs", type=int, default=None, help="environments per GPU (default: the config's)")
     ap.add_argument("--max-steps", type=int, default=None)
+    ap.add_argument("--update-group", default=None, help="runtime.update_group: mini-batches per autograd graph of the update (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 measurement that rides along with cfg2")
     ap.add_argument("--tick-samples", type=int, default=150)
@@ -455,18 +459,18 @@ def main():
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64 environment / f32 policy", "data": "synthetic (seeded random maps, random-init weights)",
             "config": {"workload": main_res["workload"], "envs_per_gpu": main_res["envs_per_gpu"], "episode_steps": main_res["episode_steps"],
-                       "mini_batch_size": main_res["mini_batch_size"],
+                       "mini_batch_size": main_res["mini_batch_size"], "update_group": main_res["update_group"],
                        "parallelism": f"dp{world} ({args.scaling} scaling: " + (f"{main_res['envs_per_gpu'] * world} environments in total, {main_res['envs_per_gpu']} per rank)"
                                                                                  if args.scaling == "strong" else f"{main_res['envs_per_gpu']} environments on every rank)"),
                        "collective": (f"torch.distributed {main_res['backend']} all_reduce(SUM) of one flat fp32 gradient bucket per epoch"
                                       if world > 1 else None)},
-            "ppo_updates_per_s": main_res["ppo_updates_per_s"], "breakdown_ms": main_res["breakdown_ms"],
+            "ppo_updates_per_s": main_res["ppo_updates_per_s"], "breakdown_ms": main_res["breakdown_ms"], "hbm_peak_GB": main_res["hbm_peak_GB"],
             "roofline": main_res["roofline"], "roofline_packed_rows": main_res["roofline_packed_rows"],
             "roofline_iteration": main_res["roofline_iteration"], "roofline_replan_tick": main_res["roofline_replan_tick"],
             "roofline_compute_kernels": main_res.get("roofline_compute_kernels", {}),
         }
         if second is not None:
-            out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "workload", "roofline_iteration")}}
+            out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "hbm_peak_GB", "workload", "roofline_iteration")}}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -1071,7 +1071,7 @@ __device__ __forceinline__ int gc_idx(int row, int k) { return ((k >> 5) * GRU_R
 // Several independent cells of one shape (the actor's and the critic's layer of the same depth) as ONE launch: blockIdx.y selects the
 // cell, the persistent workgroups are divided between them.  Every workgroup pays the weight prologue (393 KB from L2) once per
 // launch; two cells in one launch halve the prologues per tile and the launches per tick.
-struct GruCellNets { mo_gru_cell_net n[MO_GRU_MAX_NETS]; };
+struct GruCellNets { mo_gru_cell_net n[MO_GRU_CELL_MAX_NETS]; };
 
 __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, GruCellNets nets) {
     const mo_gru_cell_net &net = nets.n[blockIdx.y];
@@ -1209,8 +1209,10 @@ __device__ __forceinline__ int gru2_hidx(int row, int k) { return ((k >> 5) * GR
 struct GruFwdNets { mo_gru_seq_net n[MO_GRU_MAX_NETS]; };
 struct GruBwdNets { mo_gru_seq_bwd_net n[MO_GRU_MAX_NETS]; };
 
-__global__ __launch_bounds__(512) void k_gru_seq_fwd2(int T, int B, GruFwdNets nets, int gi_agents) {
+__global__ __launch_bounds__(512) void k_gru_seq_fwd2(int T, int Bmax, GruFwdNets nets, int gi_agents) {
     const mo_gru_seq_net &net = nets.n[blockIdx.y];
+    const int B = net.B > 0 ? net.B : Bmax;                      // layers of one launch may differ in their number of sequences
+    if ((int)blockIdx.x * GRU_RB >= B) return;                    // (uniform per workgroup, before any barrier)
     const float *__restrict__ gi = net.gi, *__restrict__ w_hh = net.w_hh, *__restrict__ b_hh = net.b_hh, *__restrict__ h0 = net.h0;
     float *__restrict__ out = net.out, *__restrict__ save = net.save;
     __shared__ __attribute__((aligned(16))) float hs[2][4 * GRU_RB * GRU2_LD];
@@ -1241,7 +1243,7 @@ __global__ __launch_bounds__(512) void k_gru_seq_fwd2(int T, int B, GruFwdNets n
     }
     lds_barrier();
     const int hpos = gru2_hidx(row, u0);
-    const size_t nblk = gridDim.x;
+    const size_t nblk = (size_t)(B + GRU_RB - 1) / GRU_RB;   // of THIS layer (the save area is laid out per layer)
     float4 *sv = save ? (float4 *)save + (size_t)blockIdx.x * 4 * 512 + tid : nullptr;
     int cur = 0;
     for (int t = 0; t < T; t++) {
@@ -1283,8 +1285,10 @@ __global__ __launch_bounds__(512) void k_gru_seq_fwd2(int T, int B, GruFwdNets n
     }
 }
 
-__global__ __launch_bounds__(512) void k_gru_seq_bwd2(int T, int B, GruBwdNets nets, int gi_agents) {
+__global__ __launch_bounds__(512) void k_gru_seq_bwd2(int T, int Bmax, GruBwdNets nets, int gi_agents) {
     const mo_gru_seq_bwd_net &net = nets.n[blockIdx.y];
+    const int B = net.B > 0 ? net.B : Bmax;
+    if ((int)blockIdx.x * GRU_RB >= B) return;
     const float *__restrict__ dout = net.dout, *__restrict__ save = net.save, *__restrict__ out = net.out, *__restrict__ h0 = net.h0,
                 *__restrict__ w_hh = net.w_hh;
     float *__restrict__ dgi = net.dgi, *__restrict__ dgh = net.dgh, *__restrict__ dnr_out = net.dnr, *__restrict__ dh0 = net.dh0;
@@ -1306,7 +1310,7 @@ __global__ __launch_bounds__(512) void k_gru_seq_bwd2(int T, int B, GruBwdNets n
         const int k0 = GRU_H * g + u0;
         gpos[g] = ((k0 / 96) * GRU_RB + row) * GRU2_LD3 + k0 % 96;
     }
-    const size_t nblk = gridDim.x;
+    const size_t nblk = (size_t)(B + GRU_RB - 1) / GRU_RB;   // of THIS layer (the save area is laid out per layer)
     const float4 *sv = (const float4 *)save + (size_t)blockIdx.x * 4 * 512 + tid;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sb_r = zero4, sb_z = zero4, sb_n = zero4, sb_nr = zero4;
@@ -2144,7 +2148,7 @@ int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, 
 }
 
 int gru_cell_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, int32_t H, void *stream) {
-    if (n_nets < 1 || n_nets > MO_GRU_MAX_NETS || !nets || B < 1 || H != GRU_H) return MO_ERR_BAD_ARG;
+    if (n_nets < 1 || n_nets > MO_GRU_CELL_MAX_NETS || !nets || B < 1 || H != GRU_H) return MO_ERR_BAD_ARG;
     GruCellNets a;
     memset(&a, 0, sizeof a);
     for (int k = 0; k < n_nets; k++) {
@@ -2179,6 +2183,7 @@ int gru_seq_fwd_multi(int32_t n_nets, const mo_gru_seq_net *nets, int32_t T, int
         const mo_gru_seq_net &m = nets[k];
         if (!m.gi || !m.w_hh || !m.b_hh || !m.h0 || !m.out) return MO_ERR_BAD_ARG;
         if ((((uintptr_t)m.gi | (uintptr_t)m.w_hh | (uintptr_t)m.b_hh | (uintptr_t)m.h0 | (uintptr_t)m.out | (uintptr_t)m.save) & 15)) return MO_ERR_BAD_ARG;
+        if (m.B < 0 || m.B > B || (gi_agents && m.B % gi_agents)) return MO_ERR_BAD_ARG;
         a.n[k] = m;
     }
     const int nblk = (B + GRU_RB - 1) / GRU_RB;
@@ -2188,7 +2193,7 @@ int gru_seq_fwd_multi(int32_t n_nets, const mo_gru_seq_net *nets, int32_t T, int
 
 int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
                 float *save, int32_t gi_agents, void *stream) {
-    const mo_gru_seq_net net{gi, w_hh, b_hh, h0, out, save};
+    const mo_gru_seq_net net{gi, w_hh, b_hh, h0, out, save, 0, 0};
     return gru_seq_fwd_multi(1, &net, T, B, H, gi_agents, stream);
 }
 
@@ -2205,20 +2210,23 @@ int gru_seq_bwd_multi(int32_t n_nets, const mo_gru_seq_bwd_net *nets, int32_t T,
         if ((m.db_ih || m.db_hh) && (!m.db_ih || !m.db_hh || !m.workspace)) return MO_ERR_BAD_ARG;
         if ((((uintptr_t)m.dout | (uintptr_t)m.save | (uintptr_t)m.out | (uintptr_t)m.h0 | (uintptr_t)m.dgi | (uintptr_t)m.dgh | (uintptr_t)m.dnr |
               (uintptr_t)m.dh0 | (uintptr_t)m.workspace) & 15)) return MO_ERR_BAD_ARG;
+        if (m.B < 0 || m.B > B || (gi_agents && m.B % gi_agents)) return MO_ERR_BAD_ARG;
         a.n[k] = m;
     }
     const int nblk = (B + GRU_RB - 1) / GRU_RB;
     hipLaunchKernelGGL(k_gru_seq_bwd2, dim3(nblk, n_nets), dim3(512), 0, (hipStream_t)stream, T, B, a, (int)gi_agents);
     for (int k = 0; k < n_nets; k++)
-        if (nets[k].db_ih)
-            hipLaunchKernelGGL(k_gru_bias_reduce, dim3(4 * GRU_H / 4), dim3(256), 0, (hipStream_t)stream, nblk, (const float *)nets[k].workspace, nets[k].db_ih,
+        if (nets[k].db_ih) {
+            const int nb = ((nets[k].B > 0 ? nets[k].B : B) + GRU_RB - 1) / GRU_RB;
+            hipLaunchKernelGGL(k_gru_bias_reduce, dim3(4 * GRU_H / 4), dim3(256), 0, (hipStream_t)stream, nb, (const float *)nets[k].workspace, nets[k].db_ih,
                                nets[k].db_hh);
+        }
     return (int)hipGetLastError();
 }
 
 int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float *save, const float *out, const float *h0, const float *w_hh,
                 float *dgi, float *dgh, float *dnr, float *dh0, float *db_ih, float *db_hh, int32_t gi_agents, void *workspace, void *stream) {
-    const mo_gru_seq_bwd_net net{dout, save, out, h0, w_hh, dgi, dgh, dnr, dh0, db_ih, db_hh, workspace};
+    const mo_gru_seq_bwd_net net{dout, save, out, h0, w_hh, dgi, dgh, dnr, dh0, db_ih, db_hh, workspace, 0, 0};
     return gru_seq_bwd_multi(1, &net, T, B, H, gi_agents, stream);
 }
 

@@ -8,11 +8,14 @@ quirks that change numbers are reproduced when `runtime.reference_quirks` is tru
 shared by actor and critic during rollouts and the critic's all-ones adjacency over padded obstacle
 slots in training only (Q5).
 """
+import contextlib
+import types
+
 import numpy as np
 import torch
 
 from . import ops
-from .model import build_actor_critic, sequence_forward_pair
+from .model import build_actor_critic, pair_embeddings, pair_heads, sequence_forward_pair
 from .pe_env import status_or, status_text
 
 BUFFER_KEYS = ("p_state", "e_state", "o_state", "p_adj", "e_adj", "o_adj", "actor_historical_embedding",
@@ -130,6 +133,65 @@ class BigBuffer:
         return self.buffer
 
 
+class _SegmentParams:
+    """G sets of detached aliases of the trained parameters -- same storage, they ARE the weights -- each set with its own
+    gradient storage.  The mini-batches of a group run forward and backward as ONE autograd graph (their GRU recurrences share
+    launches, MAPPO._train_grouped) and still deliver their gradients separately, which the clip of the running sum after every
+    mini-batch needs.  `use(k)` makes set k the modules' parameters for the duration of a forward."""
+
+    def __init__(self, modules, params, G):
+        self.params = list(params)
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(G, total, dtype=torch.float32, device=self.params[0].device)
+        self.sets = [[p.detach().requires_grad_() for p in self.params] for _ in range(G)]
+        self.attach()
+        index = {id(p): i for i, p in enumerate(self.params)}
+        self.owners, seen = [], set()
+        for root in modules:
+            for m in root.modules():
+                for name, p in m._parameters.items():
+                    if p is not None and id(p) in index and (id(m), name) not in seen:
+                        seen.add((id(m), name))
+                        self.owners.append((m, name, index[id(p)]))
+
+    def attach(self):
+        for k, aliases in enumerate(self.sets):
+            o = 0
+            for a in aliases:
+                a.grad = self.flat[k, o:o + a.numel()].view_as(a)
+                o += a.numel()
+
+    def stale(self):
+        """a parameter's storage was replaced since the aliases were made (module.to(), load of a whole module)"""
+        return any(a.data_ptr() != p.data_ptr() for a, p in zip(self.sets[0], self.params))
+
+    def zero(self):
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
+        if any(a.grad is None or not lo <= a.grad.data_ptr() < hi for aliases in self.sets for a in aliases):
+            self.attach()
+        self.flat.zero_()
+
+    def grads(self, k):
+        return [a.grad for a in self.sets[k]]
+
+    @contextlib.contextmanager
+    def use(self, k):
+        aliases = self.sets[k]
+        for m, name, i in self.owners:
+            m._parameters[name] = aliases[i]
+        try:
+            yield
+        finally:
+            for m, name, i in self.owners:
+                m._parameters[name] = self.params[i]
+
+
+def _gru_weights(gru):
+    """the torch.nn.GRU attributes ops.gru_multi reads, as they are bound right now (inside _SegmentParams.use: one set's aliases)"""
+    names = [f"{kind}_l{layer}" for layer in range(gru.num_layers) for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    return types.SimpleNamespace(num_layers=gru.num_layers, **{n: getattr(gru, n) for n in names})
+
+
 class MAPPO:
     def __init__(self, cfg, batch_size, mini_batch_size, agent_type):
         self.batch_size = batch_size
@@ -168,6 +230,9 @@ class MAPPO:
         # Trainer / Worker before the first rollout; the counter itself is part of the resume bundle.
         self.sample_rank = int(rt.get("sample_rank", 0))
         self.use_graphs = bool(rt.get("use_graphs", True))
+        ug = rt.get("update_group", "auto")    # mini-batches per autograd graph in train(): "auto" | int (see _update_group)
+        self.update_group = "auto" if str(ug) == "auto" else int(ug)
+        self.update_group_max_GB = float(rt.get("update_group_max_GB", 200.0))
         # depth 0: nothing reads buffer["{actor,critic}_historical_embedding"], so the rollout does not fill them (they stay zero;
         # the reference stores every tick's embedding regardless, DHGN/mappo_parallel.py:795-798).  true = record them anyway.
         self.record_unused_embeddings = bool(rt.get("record_unused_embeddings", False))
@@ -189,29 +254,22 @@ class MAPPO:
             self.grad_bucket.zero()          # persistent flat gradient storage (trainer.GradBucket): zeroed, not dropped
         else:
             self.ac_optimizer.zero_grad()
-        d = self.depth
-        for n0 in range(0, N, self.mini_batch_size):  # BatchSampler(SequentialSampler, mini_batch_size, drop_last=False)
+        starts = list(range(0, N, self.mini_batch_size))  # BatchSampler(SequentialSampler, mini_batch_size, drop_last=False)
+        G = self._update_group(len(starts), min(self.mini_batch_size, N) * P, T)
+        if G > 1:
+            object_critics, object_actors = self._train_grouped(batch, o_static, adv, v_target, starts, G)
+            update_time = len(starts)
+            starts = []
+        for n0 in starts:
             n1 = min(n0 + self.mini_batch_size, N)
             mb = n1 - n0
-            R = mb * T
-            obs = dict(p_state=batch["p_state"][n0:n1].reshape(R, P, -1), e_state=batch["e_state"][n0:n1].reshape(R, 1, -1),
-                       o_state=o_static[n0:n1], q_div=T, p_adj=batch["p_adj"][n0:n1].reshape(R, P, P),
-                       e_adj=batch["e_adj"][n0:n1].reshape(R, P, 1), o_adj_bits=batch["o_adj_bits"][n0:n1].reshape(R, P, -1))
-            # EmbeddingDataset2 (:95-113): hop k reads the stored embeddings of step t-1-k (clean per-net history)
-            # (the (mb, T, P, E) slices are read in place by the neighbour-mean kernel: no gathered copies)
-            hist_a = [batch["actor_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T] for k in range(d)]
-            hist_c = [batch["critic_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T] for k in range(d)]
+            obs, hist_a, hist_c = self._minibatch_inputs(batch, o_static, n0, n1)
             # One stream: running the critic branch beside the actor's on a second stream was tried in round 1 and removed --
             # it put two library GEMMs in flight at once, and with DHGN depth > 0 at 4096 environments the update stopped making
             # progress ("two-stream update").  A whole-device library GEMM is not a kernel to co-schedule.
             # actor and critic together: their GRU recurrences share one launch per layer and direction (model.sequence_forward_pair)
             prob, values_now = sequence_forward_pair(self.actor, self.critic, obs, hist_a, hist_c, mb, T)
-            dist = torch.distributions.Categorical(prob)      # get_logprob_and_entropy (:451-456)
-            a_logprob_n_now, dist_entropy = dist.log_prob(batch["a_n"][n0:n1]), dist.entropy()
-            values_now = values_now.squeeze(-1)
-            actor_loss, critic_loss = ops.ppo_loss(a_logprob_n_now, dist_entropy, values_now, batch["a_logprob_n"][n0:n1], adv[n0:n1],
-                                                   batch["active"][n0:n1], batch["v_n"][n0:n1, :-1] if self.use_value_clip else None,
-                                                   v_target[n0:n1], self.epsilon, self.entropy_coef, self.use_value_clip)
+            actor_loss, critic_loss = self._minibatch_losses(batch, adv, v_target, n0, n1, prob, values_now)
             (actor_loss + critic_loss).backward()
             if self.use_grad_clip:  # on the gradients accumulated so far, after every mini-batch
                 torch.nn.utils.clip_grad_norm_(self.ac_parameters, 5.0)
@@ -224,6 +282,88 @@ class MAPPO:
         if not return_grads:  # device-side path: gradients stay in .grad for the flat all-reduce
             return object_critics / update_time, object_actors / update_time, None, None
         return object_critics / update_time, object_actors / update_time, self.actor.get_gradients(), self.critic.get_gradients()
+
+    def _minibatch_inputs(self, batch, o_static, n0, n1):
+        """rows [n0, n1) of the buffer as one sequence batch: (obs dict, actor history slices, critic history slices)"""
+        T, P, d = batch["r"].shape[1], batch["r"].shape[2], self.depth
+        R = (n1 - n0) * T
+        obs = dict(p_state=batch["p_state"][n0:n1].reshape(R, P, -1), e_state=batch["e_state"][n0:n1].reshape(R, 1, -1),
+                   o_state=o_static[n0:n1], q_div=T, p_adj=batch["p_adj"][n0:n1].reshape(R, P, P),
+                   e_adj=batch["e_adj"][n0:n1].reshape(R, P, 1), o_adj_bits=batch["o_adj_bits"][n0:n1].reshape(R, P, -1))
+        # EmbeddingDataset2 (:95-113): hop k reads the stored embeddings of step t-1-k (clean per-net history)
+        # (the (mb, T, P, E) slices are read in place by the neighbour-mean kernel: no gathered copies)
+        hist_a = [batch["actor_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T] for k in range(d)]
+        hist_c = [batch["critic_historical_embedding"][n0:n1, d - 1 - k: d - 1 - k + T] for k in range(d)]
+        return obs, hist_a, hist_c
+
+    def _minibatch_losses(self, batch, adv, v_target, n0, n1, prob, values_now):
+        dist = torch.distributions.Categorical(prob)      # get_logprob_and_entropy (:451-456)
+        a_logprob_n_now, dist_entropy = dist.log_prob(batch["a_n"][n0:n1]), dist.entropy()
+        return ops.ppo_loss(a_logprob_n_now, dist_entropy, values_now.squeeze(-1), batch["a_logprob_n"][n0:n1], adv[n0:n1],
+                            batch["active"][n0:n1], batch["v_n"][n0:n1, :-1] if self.use_value_clip else None,
+                            v_target[n0:n1], self.epsilon, self.entropy_coef, self.use_value_clip)
+
+    def _update_group(self, n_minibatches, rows, T):
+        """how many consecutive mini-batches run as one autograd graph (`runtime.update_group`: an int, or "auto" = all of them:
+        at a data-parallel rank's share of the batch ten launches of 26 workgroups each take as long as ten launches of 205 do,
+        and at the full batch 10 x 2 x 205 workgroups in one launch fill the last round of the 256 CUs that 20 launches leave
+        a fifth empty).  The activations of a group are alive together -- measured 25 KB per GRU row and step at depth 0, 35 KB
+        at depth 3 (125 / 171 GB for the 4096-environment benchmark batch against 17.5 / 25 GB for the loop) --;
+        `runtime.update_group_max_GB` (default 200 of the 288 GB) bounds the estimate."""
+        if n_minibatches < 2 or not (self.actor.use_rnn and self.critic.use_rnn) or T < ops.PERSISTENT_GRU_MIN_T or self.device.type != "cuda":
+            return 1
+        per_minibatch = rows * T * (26e3 + 3.2e3 * self.depth)
+        cap = min(n_minibatches, ops.GRU_MULTI_MAX_NETS // 2, max(1, int(self.update_group_max_GB * 1e9 / per_minibatch)))
+        if self.update_group == "auto":
+            return cap
+        return max(1, min(int(self.update_group), cap))
+
+    def _train_grouped(self, batch, o_static, adv, v_target, starts, G):
+        """The update's mini-batches in groups of G: the weights are the same for all of them (one optimiser step per update,
+        after the last mini-batch), so a group's forward passes are independent and run as one autograd graph in which the GRU
+        recurrences of ALL its mini-batches (both networks) share one persistent launch per layer and direction.  Each mini-batch
+        differentiates its own aliases of the parameters (_SegmentParams), so its gradient arrives separately and the
+        accumulate-then-clip sequence over mini-batches (Q9) is replayed afterwards in order: same numbers as the loop in
+        train(), bit for bit."""
+        N, T, P = batch["r"].shape
+        segs = getattr(self, "_segs", None)
+        if segs is None or len(segs.sets) < G or segs.stale():
+            segs = self._segs = _SegmentParams((self.actor, self.critic), self.ac_parameters, G)
+        main_grads = [p.grad for p in self.ac_parameters]
+        if any(g is None for g in main_grads):
+            for p in self.ac_parameters:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            main_grads = [p.grad for p in self.ac_parameters]
+        object_critics = object_actors = 0.0
+        H = self.actor.rnn_hidden_dim
+        for g0 in range(0, len(starts), G):
+            group = [(n0, min(n0 + self.mini_batch_size, N)) for n0 in starts[g0:g0 + G]]
+            segs.zero()
+            xs, mods = [], []
+            for k, (n0, n1) in enumerate(group):
+                obs, hist_a, hist_c = self._minibatch_inputs(batch, o_static, n0, n1)
+                with segs.use(k):
+                    emb_a, emb_c = pair_embeddings(self.actor, self.critic, obs, hist_a, hist_c)
+                    mods += [_gru_weights(self.actor.GRU), _gru_weights(self.critic.GRU)]
+                rows = (n1 - n0) * T * P
+                xs += [emb_a.reshape(rows, self.actor.rnn_input_dim), emb_c.reshape(rows, self.critic.rnn_input_dim)]
+            h0s = [torch.zeros(m.num_layers, x.shape[0] // T, H, dtype=x.dtype, device=x.device) for x, m in zip(xs, mods)]
+            feats = ops.gru_multi(xs, h0s, mods, agents=P, steps=T, grouped=True)
+            losses = []
+            for k, (n0, n1) in enumerate(group):
+                mb = n1 - n0
+                with segs.use(k):
+                    prob, values_now = pair_heads(self.actor, self.critic, feats[2 * k].reshape(T, mb, P, H), feats[2 * k + 1].reshape(T, mb, P, H))
+                losses.append(self._minibatch_losses(batch, adv, v_target, n0, n1, prob, values_now))
+            torch.autograd.backward([l for pair in losses for l in pair])
+            for k, (actor_loss, critic_loss) in enumerate(losses):
+                torch._foreach_add_(main_grads, segs.grads(k))
+                if self.use_grad_clip:  # on the gradients accumulated so far, after every mini-batch (SURVEY Q9)
+                    torch.nn.utils.clip_grad_norm_(self.ac_parameters, 5.0)
+                object_critics = object_critics + critic_loss.detach().double()
+                object_actors = object_actors + actor_loss.detach().double()
+        return object_critics, object_actors
 
     def lr_decay(self, total_steps):
         lr_now = self.lr * (1 - total_steps / self.max_train_steps)

@@ -302,19 +302,29 @@ class SharedCritic(_Trunk):
         return self.Mean(feat).permute(1, 0, 2, 3)
 
 
-def sequence_forward_pair(actor, critic, obs, hist_a, hist_c, batch, steps):
-    """SharedActor.forward(mode 1) and SharedCritic.forward(mode 1) of one mini-batch together (DHGN/mappo_parallel.py:426-437,
-    :503-520): the two encoders as before, then the two GRUs layer by layer with actor and critic in ONE persistent launch each way
-    (ops.gru_multi) -- same numbers as the two module calls.  -> (prob (batch, steps, P, A), values (batch, steps, P, 1))."""
+def pair_embeddings(actor, critic, obs, hist_a, hist_c):
+    """the encoder half of sequence_forward_pair: (emb_a, emb_c), rows in (episode, step, agent) order"""
     enc, q_div = actor.shared_net, obs.get("q_div", 1)
     if (enc is critic.shared_net and isinstance(enc, DHGN) and obs["p_adj"].dtype == torch.float32
             and ops.msg_agg3_pair_train_ok(obs["p_state"], obs["o_state"], enc.MSG_layers[2].weight, q_div)):
         # shared DHGN: one message pass for both networks, forward and backward
         h0a, h0c = enc.encoder_pair_train(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), q_div)
-        emb_a, emb_c = enc.fcra(h0a, hist_a, obs["p_adj"], False), enc.fcra(h0c, hist_c, obs["p_adj"], True)
-    else:
-        emb_a = actor.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_a, False, None, q_div, None)
-        emb_c = critic.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_c, True, None, q_div, None)
+        return enc.fcra(h0a, hist_a, obs["p_adj"], False), enc.fcra(h0c, hist_c, obs["p_adj"], True)
+    emb_a = actor.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_a, False, None, q_div, None)
+    emb_c = critic.shared_net(obs["p_state"], obs["e_state"], obs["o_state"], obs["p_adj"], obs["e_adj"], _o_adj(obs), hist_c, True, None, q_div, None)
+    return emb_a, emb_c
+
+
+def pair_heads(actor, critic, feat_a, feat_c):
+    """the output layers on time-major GRU features (steps, batch, P, H) -> prob (batch, steps, P, A), values (batch, steps, P, 1)"""
+    return torch.softmax(actor.Mean(feat_a), dim=-1).permute(1, 0, 2, 3), critic.Mean(feat_c).permute(1, 0, 2, 3)
+
+
+def sequence_forward_pair(actor, critic, obs, hist_a, hist_c, batch, steps):
+    """SharedActor.forward(mode 1) and SharedCritic.forward(mode 1) of one mini-batch together (DHGN/mappo_parallel.py:426-437,
+    :503-520): the two encoders as before, then the two GRUs layer by layer with actor and critic in ONE persistent launch each way
+    (ops.gru_multi) -- same numbers as the two module calls.  -> (prob (batch, steps, P, A), values (batch, steps, P, 1))."""
+    emb_a, emb_c = pair_embeddings(actor, critic, obs, hist_a, hist_c)
     P = emb_a.shape[1]
     if not (actor.use_rnn and critic.use_rnn):
         feat_a, feat_c = actor._sequence_features(emb_a, batch, steps), critic._sequence_features(emb_c, batch, steps)
@@ -323,9 +333,7 @@ def sequence_forward_pair(actor, critic, obs, hist_a, hist_c, batch, steps):
         fa, fc = ops.gru_multi([emb_a.reshape(batch * steps * P, actor.rnn_input_dim), emb_c.reshape(batch * steps * P, critic.rnn_input_dim)],
                                h0, [actor.GRU, critic.GRU], agents=P, steps=steps)
         feat_a, feat_c = fa.reshape(steps, batch, P, actor.rnn_hidden_dim), fc.reshape(steps, batch, P, critic.rnn_hidden_dim)
-    prob = torch.softmax(actor.Mean(feat_a), dim=-1).permute(1, 0, 2, 3)
-    values = critic.Mean(feat_c).permute(1, 0, 2, 3)
-    return prob, values
+    return pair_heads(actor, critic, feat_a, feat_c)
 
 
 def build_actor_critic(cfg, device):

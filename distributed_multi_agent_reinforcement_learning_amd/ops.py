@@ -1108,29 +1108,32 @@ def gru_step_multi(xs, hiddens, modules):
 
 
 GRU_MULTI_MAX_WORKGROUPS = 256   # CUs of an MI355X: one persistent workgroup each
+GRU_MULTI_MAX_NETS = 24          # include/mappo_ops.h MO_GRU_MAX_NETS
 
 
 class GruSeqNet(C.Structure):
     """include/mappo_ops.h mo_gru_seq_net"""
-    _fields_ = [(n, C.c_void_p) for n in ("gi", "w_hh", "b_hh", "h0", "out", "save")]
+    _fields_ = [(n, C.c_void_p) for n in ("gi", "w_hh", "b_hh", "h0", "out", "save")] + [("B", C.c_int32), ("pad0", C.c_int32)]
 
 
 class GruSeqBwdNet(C.Structure):
     """include/mappo_ops.h mo_gru_seq_bwd_net"""
-    _fields_ = [(n, C.c_void_p) for n in ("dout", "save", "out", "h0", "w_hh", "dgi", "dgh", "dnr", "dh0", "db_ih", "db_hh", "workspace")]
+    _fields_ = ([(n, C.c_void_p) for n in ("dout", "save", "out", "h0", "w_hh", "dgi", "dgh", "dnr", "dh0", "db_ih", "db_hh", "workspace")]
+                + [("B", C.c_int32), ("pad0", C.c_int32)])
 
 
 class _GRULayerMulti(torch.autograd.Function):
-    """The same layer of several independent GRUs (the actor's and the critic's: own weights, own inputs, same T, B and row order)
-    with the recurrences of all of them in ONE persistent launch each way (gru_seq_fwd_multi / gru_seq_bwd_multi); per network the
-    arithmetic is that of _GRULayer's persistent path.  args: T, B, agents, then per network (x, h0, w_ih, w_hh, b_ih, b_hh)."""
+    """The same layer of several independent GRUs (the actor's and the critic's, for one or several mini-batches: own weights, own
+    inputs, own number of sequences; same T and row order) with the recurrences of all of them in ONE persistent launch each way
+    (gru_seq_fwd_multi / gru_seq_bwd_multi); per network the arithmetic is that of _GRULayer's persistent path.
+    args: T, Bs (sequences per network), agents, then per network (x, h0, w_ih, w_hh, b_ih, b_hh)."""
 
     @staticmethod
-    def forward(ctx, T, B, agents, *ts):
+    def forward(ctx, T, Bs, agents, *ts):
         L = load_library()
         n = len(ts) // 6
         H = ts[3].shape[1]
-        assert H == 128 and T >= PERSISTENT_GRU_MIN_T and len(ts) == 6 * n
+        assert H == 128 and T >= PERSISTENT_GRU_MIN_T and len(ts) == 6 * n and len(Bs) == n
         need = any(ctx.needs_input_grad)
         outs, saved = [], []
         arr = (GruSeqNet * n)()
@@ -1138,7 +1141,7 @@ class _GRULayerMulti(torch.autograd.Function):
         for k in range(n):
             x, h0, w_ih, w_hh, b_ih, b_hh = ts[6 * k: 6 * k + 6]
             _need_gpu(x, "gru")
-            I = x.shape[-1]
+            I, B = x.shape[-1], Bs[k]
             x, h0 = x.contiguous(), h0.contiguous()
             out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
             gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())
@@ -1147,11 +1150,12 @@ class _GRULayerMulti(torch.autograd.Function):
             a = arr[k]
             a.gi, a.w_hh, a.b_hh, a.h0, a.out = gi.data_ptr(), whh.data_ptr(), bhh.data_ptr(), h0.data_ptr(), out.data_ptr()
             a.save = save.data_ptr() if need else None
+            a.B = B
             keep.append((gi, whh, bhh))
             outs.append(out)
             saved += [x, h0, w_ih, whh, out, save]
-        _check(L.gru_seq_fwd_multi(n, C.cast(arr, C.c_void_p), T, B, H, int(agents), _stream()), "gru_seq_fwd_multi")
-        ctx.dims, ctx.agents, ctx.n = (T, B), int(agents), n
+        _check(L.gru_seq_fwd_multi(n, C.cast(arr, C.c_void_p), T, max(Bs), H, int(agents), _stream()), "gru_seq_fwd_multi")
+        ctx.dims, ctx.agents, ctx.n = (T, tuple(Bs)), int(agents), n
         ctx.x_shapes = [ts[6 * k].shape for k in range(n)]
         if need:
             ctx.save_for_backward(*saved)
@@ -1160,7 +1164,7 @@ class _GRULayerMulti(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *douts):
         L = load_library()
-        T, B = ctx.dims
+        T, Bs = ctx.dims
         n = ctx.n
         sv = ctx.saved_tensors
         H = 128
@@ -1169,7 +1173,7 @@ class _GRULayerMulti(torch.autograd.Function):
         per = []
         for k in range(n):
             x, h0, w_ih, w_hh, out, save = sv[6 * k: 6 * k + 6]
-            dev, dt = x.device, x.dtype
+            dev, dt, B = x.device, x.dtype, Bs[k]
             dout = douts[k].contiguous()
             dgi = torch.empty((T * B, 3 * H), dtype=dt, device=dev)
             dgh = None if split else torch.empty((T, B, 3 * H), dtype=dt, device=dev)
@@ -1182,12 +1186,14 @@ class _GRULayerMulti(torch.autograd.Function):
             a.dgh = dgh.data_ptr() if dgh is not None else None
             a.dnr = dnr.data_ptr() if dnr is not None else None
             a.dh0, a.db_ih, a.db_hh, a.workspace = dh0.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), ws.data_ptr()
+            a.B = B
             per.append((dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws))
-        _check(L.gru_seq_bwd_multi(n, C.cast(arr, C.c_void_p), T, B, H, ctx.agents, _stream()), "gru_seq_bwd_multi")
+        _check(L.gru_seq_bwd_multi(n, C.cast(arr, C.c_void_p), T, max(Bs), H, ctx.agents, _stream()), "gru_seq_bwd_multi")
         grads = [None, None, None]
         for k in range(n):
             x, h0, w_ih, w_hh, out, save = sv[6 * k: 6 * k + 6]
             dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws = per[k]
+            B = Bs[k]
             dw_hh = _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H)
             I = x.shape[-1]
             dw_ih = wgrad(dgi, x.reshape(T * B, I))
@@ -1214,21 +1220,25 @@ def _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H):
     return dw_hh
 
 
-def gru_multi(xs, h0s, modules, agents=0, steps=None):
-    """ops.gru for several independent GRU modules of one shape on inputs of one shape (actor and critic): layer by layer, the
-    recurrences of all modules in one launch (see _GRULayerMulti).  Returns the list of outputs (T, B, H) (no h_n: sequences start
-    from the given h0 and the final state is out[-1]).  Shapes the persistent kernels do not cover take ops.gru per module."""
+def gru_multi(xs, h0s, modules, agents=0, steps=None, grouped=False):
+    """ops.gru for several independent GRU modules of one architecture (actor and critic, for one or -- `grouped` -- several
+    mini-batches: the inputs may differ in their number of sequences): layer by layer, the recurrences of all of them in one launch
+    (see _GRULayerMulti).  `modules` need only carry num_layers and the weight_* / bias_* attributes of torch.nn.GRU.  Returns the
+    list of outputs (T, B_k, H) (no h_n: sequences start from the given h0 and the final state is out[-1]).  Shapes the persistent
+    kernels do not cover take ops.gru per module."""
     n = len(xs)
-    x0 = xs[0]
     if agents:
-        assert x0.dim() == 2 and steps and x0.shape[0] % (steps * agents) == 0
-        T, B = int(steps), x0.shape[0] // int(steps)
+        assert xs[0].dim() == 2 and steps and all(x.shape[0] % (steps * agents) == 0 for x in xs)
+        T, Bs = int(steps), [x.shape[0] // int(steps) for x in xs]
     else:
-        T, B = x0.shape[0], x0.shape[1]
-    # one launch only while all layers' workgroups (16 rows each) are resident at once: at the full benchmark mini-batch (205 + 205
-    # workgroups on 256 CUs) the second layer's workgroups would queue behind the first's anyway and the extra concurrency only adds
-    # HBM contention (measured: update +13 ms at 4096 environments, -16 ms at 512)
-    ok = (n <= 4 and T >= PERSISTENT_GRU_MIN_T and all(x.shape == x0.shape for x in xs) and n * ((B + 15) // 16) <= GRU_MULTI_MAX_WORKGROUPS
+        T, Bs = xs[0].shape[0], [x.shape[1] for x in xs]
+    tiles = sum((B + 15) // 16 for B in Bs)
+    # two layers of ONE mini-batch share a launch only while their workgroups (16 rows each) are resident at once: at the full
+    # benchmark mini-batch (205 + 205 workgroups on 256 CUs) the second layer's would queue behind the first's anyway and the extra
+    # concurrency only adds HBM contention (measured: update +13 ms at 4096 environments, -16 ms at 512).  A group of mini-batches
+    # (MAPPO.train, small batches) is launched together whatever its size: that is what fills the chip.
+    ok = (n <= GRU_MULTI_MAX_NETS and T >= PERSISTENT_GRU_MIN_T and all(x.shape[-1] == xs[0].shape[-1] and x.dim() == xs[0].dim() for x in xs)
+          and (grouped or (tiles <= GRU_MULTI_MAX_WORKGROUPS and all(B == Bs[0] for B in Bs)))
           and all(m.num_layers == modules[0].num_layers and m.weight_hh_l0.shape == (384, 128) for m in modules))
     if not ok:
         return [gru(x, h0, m, agents=agents, steps=steps)[0] for x, h0, m in zip(xs, h0s, modules)]
@@ -1238,7 +1248,7 @@ def gru_multi(xs, h0s, modules, agents=0, steps=None):
         for k, m in enumerate(modules):
             ts += [inps[k], h0s[k][layer], getattr(m, f"weight_ih_l{layer}"), getattr(m, f"weight_hh_l{layer}"),
                    getattr(m, f"bias_ih_l{layer}"), getattr(m, f"bias_hh_l{layer}")]
-        inps = list(_GRULayerMulti.apply(T, B, int(agents) if layer == 0 else 0, *ts))
+        inps = list(_GRULayerMulti.apply(T, tuple(Bs), int(agents) if layer == 0 else 0, *ts))
     return inps
 
 

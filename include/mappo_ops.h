@@ -193,16 +193,20 @@ int gru_gates_bwd(int32_t B, int32_t H, const float *dout, const float *dcarry, 
  * All pointers 16-byte aligned.
  */
 int64_t gru_seq_save_elems(int32_t T, int32_t B);
-/* Several independent layers of one shape in ONE launch (the actor's and the critic's layer of the same depth: different weights and
- * inputs, same T, B, gi_agents): at a data-parallel rank's share of the batch one layer is a few dozen workgroups that run T sequential
- * steps, and a launch takes as long as at full size; together the layers fill more of the chip in the same time.  Records of HOST
- * memory holding DEVICE pointers, meaning as in gru_seq_fwd / gru_seq_bwd. */
-#define MO_GRU_MAX_NETS 4
-typedef struct mo_gru_seq_net { const float *gi, *w_hh, *b_hh, *h0; float *out, *save; } mo_gru_seq_net;
+/* Several independent layers in ONE launch (the actor's and the critic's layer of the same depth, for every mini-batch of a group:
+ * same T and gi_agents; own weights, inputs and B): at a data-parallel rank's share of the batch one layer is a few dozen workgroups
+ * that run T sequential steps, and a launch takes as long as at full size; together the layers fill the chip in the same time.
+ * Records of HOST memory holding DEVICE pointers, meaning as in gru_seq_fwd / gru_seq_bwd. */
+#define MO_GRU_MAX_NETS 24
+#define MO_GRU_CELL_MAX_NETS 4
+/* B (per record): this layer's number of sequences, <= the launch's B argument (0: the launch's B) -- the layers of one launch may be
+ * ragged (the last mini-batch of an epoch is smaller); gi / out / save / dgi / ... of a record are sized by ITS B. */
+typedef struct mo_gru_seq_net { const float *gi, *w_hh, *b_hh, *h0; float *out, *save; int32_t B, pad0; } mo_gru_seq_net;
 typedef struct mo_gru_seq_bwd_net {
     const float *dout, *save, *out, *h0, *w_hh;
     float *dgi, *dgh, *dnr, *dh0, *db_ih, *db_hh;
     void *workspace;   /* >= gru_seq_bwd_workspace(B) bytes when db_ih / db_hh are requested; one per record */
+    int32_t B, pad0;
 } mo_gru_seq_bwd_net;
 int gru_seq_fwd_multi(int32_t n_nets, const mo_gru_seq_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream);
 int gru_seq_bwd_multi(int32_t n_nets, const mo_gru_seq_bwd_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream);
@@ -224,7 +228,7 @@ int gru_seq_bwd(int32_t T, int32_t B, int32_t H, const float *dout, const float 
 int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,
                  const float *b_hh, float *h_out, void *stream);
 /* Several independent cells of one shape (actor and critic) in ONE launch; records of HOST memory holding DEVICE pointers, meaning as
- * in gru_cell_fwd.  The persistent workgroups (one per CU) are divided between the cells. */
+ * in gru_cell_fwd (n_nets <= MO_GRU_CELL_MAX_NETS).  The persistent workgroups (one per CU) are divided between the cells. */
 typedef struct mo_gru_cell_net { const float *x, *h_prev, *w_ih, *w_hh, *b_ih, *b_hh; float *h_out; } mo_gru_cell_net;
 int gru_cell_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, int32_t H, void *stream);
 
