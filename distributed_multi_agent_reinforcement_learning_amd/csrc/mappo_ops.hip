@@ -1651,21 +1651,24 @@ __global__ __launch_bounds__(256) void k_wgrad(const float *__restrict__ A, int6
                         make_float4(acc[a][t][b][0][q], acc[a][t][b][1][q], acc[a][t][b][2][q], acc[a][t][b][3][q]);
 }
 
-// C[m][n] = (accumulate ? C[m][n] : 0) + sum_x part[x][m][n], x ascending: the same order every run
+// C[m][n] = (accumulate ? C[m][n] : 0) + sum_x part[x][m][n] in a fixed order (the same every run): wave q of a workgroup adds the
+// partials x = q, q + 4, ... of 64 outputs (8 loads in flight per lane: one thread walking all 256 partials was a 18 us chain of
+// dependent-latency loads, a quarter of the weight-gradient launch it follows at a data-parallel rank's batch), then (s0 + s1) + (s2 + s3)
 __global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float *__restrict__ part, float *__restrict__ C, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= MN) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int x = 0;
-    for (; x + 4 <= S; x += 4) {
-        s0 += part[(size_t)x * MN + idx];
-        s1 += part[(size_t)(x + 1) * MN + idx];
-        s2 += part[(size_t)(x + 2) * MN + idx];
-        s3 += part[(size_t)(x + 3) * MN + idx];
+    __shared__ float sm[4][64];
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (idx < MN) {
+#pragma unroll 8
+        for (int x = q; x < S; x += 4) s += part[(size_t)x * MN + idx];
     }
-    for (; x < S; x++) s0 += part[(size_t)x * MN + idx];
-    const float s = (s0 + s1) + (s2 + s3);
-    C[idx] = accumulate ? C[idx] + s : s;
+    sm[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && idx < MN) {
+        const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        C[idx] = accumulate ? C[idx] + t : t;
+    }
 }
 
 // ---- neighbour mean of the fixed-depth recursive aggregation (DHGN.fcra, DHGN/mappo_parallel.py:204-233) ----------------------
@@ -2248,7 +2251,7 @@ int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const
     if (am == 3) hipLaunchKernelGGL((k_wgrad<3, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
     else if (bn == 3) hipLaunchKernelGGL((k_wgrad<1, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
     else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((M * N + 63) / 64), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate);
     return (int)hipGetLastError();
 }
 
