@@ -156,6 +156,19 @@ def measure_compute_kernels(trainer, cfg):
         t = timeit(lambda: L.gru_seq_fwd(T, B, 128, ptr(gi), ptr(w), ptr(b), ptr(h0[0]), ptr(o), None, 0, st))
         out["gru_seq_fwd"] = entry("k_gru_seq_fwd2 (recurrent GEMM h W_hh^T + gates, T steps in one launch; no saved gates)", 2.0 * T * B * 128 * 384, t,
                                    rows=B, steps=T)
+        # the form the update launches (MAPPO._train_grouped): this layer of every mini-batch of the epoch and both networks at once
+        N_envs = trainer.num_envs
+        Bs = [(min(n0 + mb, N_envs) - n0) * P for n0 in range(0, N_envs, mb) for _ in range(2)]
+        if 2 <= len(Bs) <= ops.GRU_MULTI_MAX_NETS:
+            gis = [torch.randn(T, b_, 384, device=dev) for b_ in Bs]
+            os_ = [torch.empty(T, b_, 128, device=dev) for b_ in Bs]
+            arr = (ops.GruSeqNet * len(Bs))()
+            for a_, g_, o_, b_ in zip(arr, gis, os_, Bs):
+                a_.gi, a_.w_hh, a_.b_hh, a_.h0, a_.out, a_.save, a_.B = g_.data_ptr(), w.data_ptr(), b.data_ptr(), h0.data_ptr(), o_.data_ptr(), None, b_
+            t = timeit(lambda: L.gru_seq_fwd_multi(len(Bs), C.cast(arr, C.c_void_p), T, max(Bs), 128, 0, st))
+            out["gru_seq_fwd_grouped"] = entry(f"k_gru_seq_fwd2, {len(Bs)} layers (every mini-batch of the epoch x actor, critic) in one launch: "
+                                               f"{sum((b_ + 15) // 16 for b_ in Bs)} workgroups", 2.0 * T * sum(Bs) * 128 * 384, t, rows=sum(Bs), steps=T)
+            del gis, os_
         Kr = mb * T * P  # rows of one mini-batch: the weight gradient of a GRU projection reduces over all of them
         ga = torch.randn(Kr, 384, device=dev); xa = torch.randn(Kr, 128, device=dev)
         t = timeit(lambda: ops.wgrad(ga, xa))

@@ -34,6 +34,8 @@ subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), R, "--us-per-launch", f"{us32:.2f}", "--passes", "pmcf1,pmcf2",
                        "--layout", "fp32"], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "mfma_summary.py"), R], stdout=subprocess.DEVNULL)
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "mfma_summary.py"), R, "--grouped"], stdout=subprocess.DEVNULL)
+shutil.copy(newest("grug_t/**/*kernel_stats.csv"), os.path.join(P, "r03_gru_kernels_grouped_kernel_stats.csv"))
 for cfg in ("cfg2", "cfg3"):
     cat = {}
     for r in csv.DictReader(open(os.path.join(P, f"r03_bench_{cfg}_4096env_kernel_stats.csv"))):

@@ -5,17 +5,21 @@ derived-counter formula rocprofv3 lists for MfmaUtil -- next to the algorithmic 
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
-KERNELS = {"k_gru_seq_fwd2": 2.0 * 150 * 3280 * 128 * 384, "k_gru_seq_bwd2": 2.0 * 150 * 3280 * 384 * 128, "k_gru_cell": 2.0 * 32768 * 128 * 768,
-           "k_wgrad<3, 1>": 2.0 * 492000 * 384 * 128}
+GROUPED = "--grouped" in sys.argv    # <dir> holds the passes of `tools/profile_gru.py --grouped`: 18 x 3280 + 2 x 3248 sequences per launch
+ROWS = 18 * 3280 + 2 * 3248 if GROUPED else 3280
+KERNELS = {"k_gru_seq_fwd2": 2.0 * 150 * ROWS * 128 * 384, "k_gru_seq_bwd2": 2.0 * 150 * ROWS * 384 * 128}
+if not GROUPED:
+    KERNELS.update({"k_gru_cell": 2.0 * 32768 * 128 * 768, "k_wgrad<3, 1>": 2.0 * 492000 * 384 * 128})
 cnt = {}
-for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+SUB = "grug" if GROUPED else "gru"    # the passes of tools/profile_all.sh: <dir>/gru_c, gru_t (single layer), grug_c, grug_t (grouped)
+for f in glob.glob(os.path.join(d, SUB + "_c", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         for k in KERNELS:
             if k in r["Kernel_Name"]:
                 a = cnt.setdefault(k, {}).setdefault(r["Counter_Name"], [0, 0.0])
                 a[0] += 1; a[1] += float(r["Counter_Value"])
 dur = {}
-for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+for f in glob.glob(os.path.join(d, SUB + "_t", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         for k in KERNELS:
             if k in r["Name"]:
@@ -32,6 +36,11 @@ for k, fl in KERNELS.items():
         e["frac_of_157.3_TFLOPs"] = round(fl / dur[k] / 157.3e12, 4)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         e["MfmaUtil_percent"] = round(100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 2)
-    out["kernels"][k] = e
-json.dump(out, open(os.path.join(ROOT, "profiles", "r03_gru_mfma_counters.json"), "w"), indent=1)
+    out["kernels"][k + (" (grouped: 20 layers, 65 536 sequences, 4 096 workgroups per launch)" if GROUPED else "")] = e
+path = os.path.join(ROOT, "profiles", "r03_gru_mfma_counters.json")
+if GROUPED and os.path.exists(path):   # appended to the single-layer record
+    base = json.load(open(path))
+    base["kernels"].update(out["kernels"])
+    out = base
+json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))

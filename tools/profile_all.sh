@@ -12,6 +12,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcf1 -- python3 tools/prof
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcf2 -- python3 tools/profile_tick.py --float-obs > $O/pmcf2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gru_t -- python3 tools/profile_gru.py > $O/gru_t.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES --output-format csv -d $O/gru_c -- python3 tools/profile_gru.py > $O/gru_c.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/grug_t -- python3 tools/profile_gru.py --grouped > $O/grug_t.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES --output-format csv -d $O/grug_c -- python3 tools/profile_gru.py --grouped > $O/grug_c.log 2>&1
 python3 tools/bench_envs.py > $O/envs.log 2>&1
 grep "graph-replayed" $O/tick.log $O/tick_f32.log
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete

@@ -3,6 +3,8 @@ T = 150, P = 8 -> B = 3280 sequence rows; rollout B = 32768 rows) -- the target 
 counters are committed under profiles/ (north star: "rocprof-reported MFMA utilisation for the GRU GEMMs"):
   rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/profile_gru.py
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES --output-format csv -- python3 tools/profile_gru.py
+`--grouped`: the form the update launches since round 3 -- the layers of all ten mini-batches and both networks (20 x 205 workgroups,
+the last mini-batch 203) in ONE launch per direction (ops.gru_multi(grouped=True), MAPPO._train_grouped).
 Summarise with tools/mfma_summary.py."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +19,16 @@ w = lambda *s: torch.randn(*s, device=dev) * 0.08
 gm = SimpleNamespace(num_layers=1, weight_ih_l0=w(384, 128), weight_hh_l0=w(384, 128), bias_ih_l0=torch.zeros(384, device=dev), bias_hh_l0=torch.zeros(384, device=dev))
 for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
     getattr(gm, k).requires_grad_(True)
+if "--grouped" in sys.argv:
+    Bs = [3280] * 18 + [3248] * 2          # 9 mini-batches of 410 episodes and one of 406, actor and critic each
+    xs = [torch.randn(T, b, 128, device=dev, requires_grad=True) for b in Bs]
+    h0s = [torch.zeros(1, b, 128, device=dev) for b in Bs]
+    for rep in range(3):
+        outs = ops.gru_multi(xs, h0s, [gm] * len(Bs), grouped=True)
+        torch.autograd.backward([o.sum() for o in outs])
+    torch.cuda.synchronize()
+    print("done (grouped)")
+    sys.exit(0)
 x = torch.randn(T, B, 128, device=dev, requires_grad=True)
 h0 = torch.zeros(1, B, 128, device=dev)
 for rep in range(4):   # k_gru_seq_fwd + k_gru_seq_bwd + k_wgrad (the sequence mode of the update)
