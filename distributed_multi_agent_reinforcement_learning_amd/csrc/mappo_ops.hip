@@ -1184,6 +1184,166 @@ __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, GruCellNets n
 #undef GRU_STAGE
 }
 
+// ---- the rollout's GRU step in fp32 ARITHMETIC ON THE bf16 MATRIX PIPE (k_gru_cell_sb) ------------------------------------------
+// k_gru_cell is bound by v_mfma_f32_16x16x4_f32 (32 cycles per 16 x 16 x 4 step); the same silicon runs v_mfma_f32_16x16x32_bf16 in
+// 16 cycles.  Every fp32 number is EXACTLY the sum of three bf16 numbers (24 significant bits = 3 x 8, same exponent range):
+// x = x1 + x2 + x3, and a b = sum of the piece products ai bj, each exact in fp32.  Keeping the six with i + j <= 4 drops
+// a2 b3 + a3 b2 + a3 b3 < 2^-23 |a b|: one fp32 rounding of the product -- the accumulation is fp32 either way.  Six bf16 MFMAs per 32
+// contraction steps replace eight fp32 ones at half the cycles each: 2.67 x the matrix rate with fp32 inputs, fp32 outputs, and the
+// same error against f64 as the fp32 kernel (tests/test_ops_gpu.py).  Only operands are split, nothing is stored in bf16.
+// Layout: the weights of BOTH projections as three pieces each are 590 KB -- more than a CU's registers --, so a 16-row tile is
+// shared by TWO workgroups, each owning 64 hidden units (their r, z and n rows of W_ih and W_hh: 144 registers per lane as MFMA
+// A-operands, split once in the prologue).  Wave (g, role): units 16 g .. 16 g + 15 of the half; role 0 accumulates r (input +
+// recurrent product) and W_in x, role 1 z and W_hn h -- 72 MFMAs each per tile; the two roles of a unit group sit on the same SIMD,
+// role 1 hands its two accumulators over through LDS and starts the next tile's products while role 0 does the gate math.  The x
+// and h tiles are split while they are staged (one thread: 8 contraction steps of one row = one 16-byte LDS word per piece = one
+// lane's B-operand) -- double buffered, one barrier per tile.  Both workgroups read whole rows of h_prev and write half rows of
+// h_out: the state must NOT be updated in place (the rollout ping-pongs two buffers).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sb_pk(float lo, float hi) {   // two bf16 in one dword, round to nearest even (v_cvt_pk_bf16_f32)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// x = p1 + p2 + p3 exactly: p1 = bf16(x); x - p1 has <= 16 significant bits and is exact in fp32; p2 = bf16(x - p1); the rest IS a bf16
+__device__ __forceinline__ void sb_split2(float x0, float x1, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    p1 = sb_pk(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, p1 << 16), r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = sb_pk(r0, r1);
+    p3 = sb_pk(r0 - __builtin_bit_cast(float, p2 << 16), r1 - __builtin_bit_cast(float, p2 & 0xffff0000u));
+}
+// 8 consecutive contraction steps -> the three operand words of one lane
+__device__ __forceinline__ void sb_split8(const float4 &u, const float4 &v, uint4 (&p)[3]) {
+    sb_split2(u.x, u.y, p[0].x, p[1].x, p[2].x);
+    sb_split2(u.z, u.w, p[0].y, p[1].y, p[2].y);
+    sb_split2(v.x, v.y, p[0].z, p[1].z, p[2].z);
+    sb_split2(v.z, v.w, p[0].w, p[1].w, p[2].w);
+}
+// the six piece products of one 16 x 16 x 32 step, smallest first
+__device__ __forceinline__ f32x4 sb_mma6(const uint4 (&a)[3], const uint4 (&b)[3], f32x4 c) {
+#define SB_MMA(i, j) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), c, 0, 0, 0);
+    SB_MMA(2, 0) SB_MMA(0, 2) SB_MMA(1, 1) SB_MMA(1, 0) SB_MMA(0, 1) SB_MMA(0, 0)
+#undef SB_MMA
+    return c;
+}
+
+constexpr int SBC_TILE = 2 * 3 * 4 * 64;   // uint4 per staged tile: (x, h) x 3 pieces x 4 chunks of 32 steps x 64 lanes = 24 KB
+
+__global__ __launch_bounds__(512) void k_gru_cell_sb(int B, int nblk, GruCellNets nets) {
+    const mo_gru_cell_net &net = nets.n[blockIdx.y];
+    const float *__restrict__ x = net.x, *__restrict__ hprev = net.h_prev, *__restrict__ w_ih = net.w_ih, *__restrict__ w_hh = net.w_hh;
+    float *__restrict__ hout = net.h_out;
+    __shared__ uint4 tile[2][SBC_TILE];              // B-operands: [(matrix, piece, chunk)][lane]
+    __shared__ float4 hraw[2][GRU_RB * 32];          // the h tile in fp32 (the state update needs h itself)
+    __shared__ float4 xch[2][4][2][64];              // role-1 accumulators (z, W_hn h) of unit group g, per lane
+    __shared__ float4 bias_s[4][16];                 // this half's b_r (input + recurrent), b_z, b_in, b_hn
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, gq = l >> 4;
+    const int half = blockIdx.x & 1, slot = blockIdx.x >> 1, nslots = gridDim.x >> 1;
+    const int g = w & 3, role = w >> 2;
+    const int u0 = 64 * half + 16 * g;               // first hidden unit of this wave's group
+    // weights as A-operands: lane (i, gq) holds unit u0 + i, steps 32 c + 8 gq .. + 7 of chunk c
+    uint4 wa[4][3], wb[4][3], wc[4][3];
+    {
+        const float *ra = (role ? w_ih + (size_t)(GRU_H + u0 + i) * GRU_H : w_ih + (size_t)(u0 + i) * GRU_H) + 8 * gq;          // W_iz | W_ir
+        const float *rb = (role ? w_hh + (size_t)(GRU_H + u0 + i) * GRU_H : w_hh + (size_t)(u0 + i) * GRU_H) + 8 * gq;          // W_hz | W_hr
+        const float *rc = (role ? w_hh + (size_t)(2 * GRU_H + u0 + i) * GRU_H : w_ih + (size_t)(2 * GRU_H + u0 + i) * GRU_H) + 8 * gq;   // W_hn | W_in
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            sb_split8(*(const float4 *)(ra + 32 * c), *(const float4 *)(ra + 32 * c + 4), wa[c]);
+            sb_split8(*(const float4 *)(rb + 32 * c), *(const float4 *)(rb + 32 * c + 4), wb[c]);
+            sb_split8(*(const float4 *)(rc + 32 * c), *(const float4 *)(rc + 32 * c + 4), wc[c]);
+        }
+    }
+    if (tid < 64) {
+        const int u = 64 * half + tid;
+        float *bs = (float *)bias_s;
+        bs[tid] = net.b_ih[u] + net.b_hh[u];
+        bs[64 + tid] = net.b_ih[GRU_H + u] + net.b_hh[GRU_H + u];
+        bs[128 + tid] = net.b_ih[2 * GRU_H + u];
+        bs[192 + tid] = net.b_hh[2 * GRU_H + u];
+    }
+    // staging: thread -> (matrix m, 8 steps kk, row j); consecutive lanes take consecutive rows (one 16-byte LDS word each, no conflicts)
+    const int sm = tid >> 8, skk = (tid >> 4) & 15, sj = tid & 15;
+    const float *ssrc = (sm ? hprev : x) + 8 * skk;
+    const int sdst = ((sm * 3) * 4 + (skk >> 2)) * 64 + (skk & 3) * 16 + sj;     // piece p adds p * 256
+    float4 pf0, pf1;
+#define SBC_FETCH(bk)                                                                  \
+    {                                                                                  \
+        const int row_ = (bk) * GRU_RB + sj;                                           \
+        pf0 = pf1 = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+        if (row_ < B) {                                                                \
+            pf0 = *(const float4 *)(ssrc + (size_t)row_ * GRU_H);                      \
+            pf1 = *(const float4 *)(ssrc + (size_t)row_ * GRU_H + 4);                  \
+        }                                                                              \
+    }
+#define SBC_STAGE(buf)                                                                 \
+    {                                                                                  \
+        uint4 p_[3];                                                                   \
+        sb_split8(pf0, pf1, p_);                                                       \
+        tile[buf][sdst] = p_[0]; tile[buf][sdst + 256] = p_[1]; tile[buf][sdst + 512] = p_[2]; \
+        if (sm) { hraw[buf][sj * 32 + 2 * skk] = pf0; hraw[buf][sj * 32 + 2 * skk + 1] = pf1; } \
+    }
+    int blk = slot;
+    if (blk < nblk) { SBC_FETCH(blk) SBC_STAGE(0) }
+    if (blk + nslots < nblk) SBC_FETCH(blk + nslots)
+    lds_barrier();
+    int cur = 0;
+    for (; blk < nblk; blk += nslots) {
+        const int nxt = blk + nslots;
+        const uint4 *tb = tile[cur] + l;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        if (role == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                uint4 bx[3], bh[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) { bx[p] = tb[(p * 4 + c) * 64]; bh[p] = tb[((3 + p) * 4 + c) * 64]; }
+                acc0 = sb_mma6(wa[c], bx, acc0);
+                acc0 = sb_mma6(wb[c], bh, acc0);
+                acc1 = sb_mma6(wc[c], bx, acc1);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                uint4 bx[3], bh[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) { bx[p] = tb[(p * 4 + c) * 64]; bh[p] = tb[((3 + p) * 4 + c) * 64]; }
+                acc0 = sb_mma6(wa[c], bx, acc0);
+                acc0 = sb_mma6(wb[c], bh, acc0);
+                acc1 = sb_mma6(wc[c], bh, acc1);
+            }
+            xch[cur][g][0][l] = (float4){acc0[0], acc0[1], acc0[2], acc0[3]};
+            xch[cur][g][1][l] = (float4){acc1[0], acc1[1], acc1[2], acc1[3]};
+        }
+        // D layout: lane (i, gq), register q -> hidden unit u0 + 4 gq + q of batch row i
+        const float4 hp = hraw[cur][i * 32 + (u0 >> 2) + gq];     // read before the barrier: the buffer is re-staged right after it
+        if (nxt < nblk) SBC_STAGE(cur ^ 1)                        // tile `nxt` (fetched one tile ago) -> the other buffer
+        if (nxt + nslots < nblk) SBC_FETCH(nxt + nslots)          // in flight during the next tile's products
+        lds_barrier();
+        if (role == 0) {
+            const float4 zz = xch[cur][g][0][l], hn = xch[cur][g][1][l];
+            const float4 br = bias_s[0][4 * g + gq], bz = bias_s[1][4 * g + gq], bin = bias_s[2][4 * g + gq], bhn = bias_s[3][4 * g + gq];
+            float4 ho;
+#define SBC_ONE(f, q_)                                                    \
+            {                                                              \
+                const float r = sigmoid_hw(acc0[q_] + br.f);               \
+                const float z = sigmoid_hw(zz.f + bz.f);                   \
+                const float n = tanh_hw(acc1[q_] + bin.f + r * (hn.f + bhn.f)); \
+                ho.f = (1.f - z) * n + z * hp.f;                           \
+            }
+            SBC_ONE(x, 0) SBC_ONE(y, 1) SBC_ONE(z, 2) SBC_ONE(w, 3)
+#undef SBC_ONE
+            const int row = blk * GRU_RB + i;
+            if (row < B) *(float4 *)(hout + (size_t)row * GRU_H + u0 + 4 * gq) = ho;
+        }
+        cur ^= 1;
+    }
+#undef SBC_FETCH
+#undef SBC_STAGE
+}
+
 // ---- the sequence kernels: TRANSPOSED tiles ------------------------------------------------------------------------------------
 // A = weights, B = the h / dgh tile, so the MFMA result is gate^T: a lane owns FOUR CONSECUTIVE hidden units of ONE batch row
 // (rounds 1-2 computed gate[row][unit] tiles: one unit of four rows per lane, every global access a scalar in its own 64-byte
@@ -2167,6 +2327,28 @@ int gru_cell_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, i
     if (per < 1) per = 1;
     const int grid = nblk < per ? nblk : per;
     hipLaunchKernelGGL(k_gru_cell, dim3(grid, n_nets), dim3(512), 0, (hipStream_t)stream, (int)B, nblk, a);
+    return (int)hipGetLastError();
+}
+
+int gru_cell_split_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, int32_t H, void *stream) {
+    if (n_nets < 1 || n_nets > MO_GRU_CELL_MAX_NETS || !nets || B < 1 || H != GRU_H) return MO_ERR_BAD_ARG;
+    GruCellNets a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < n_nets; k++) {
+        const mo_gru_cell_net &m = nets[k];
+        if (!m.x || !m.h_prev || !m.w_ih || !m.w_hh || !m.b_ih || !m.b_hh || !m.h_out) return MO_ERR_BAD_ARG;
+        if (((uintptr_t)m.x & 15) || ((uintptr_t)m.h_prev & 15) || ((uintptr_t)m.w_ih & 15) || ((uintptr_t)m.w_hh & 15) || ((uintptr_t)m.h_out & 15))
+            return MO_ERR_BAD_ARG;
+        if (m.h_out == m.h_prev || m.h_out == m.x) return MO_ERR_BAD_ARG;   // two workgroups share a row tile: not in place
+        a.n[k] = m;
+    }
+    const int nblk = (B + GRU_RB - 1) / GRU_RB;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    int pairs = cus / n_nets / 2;   // persistent workgroup PAIRS per cell (the two halves of the hidden units): one workgroup per CU in total
+    if (pairs < 1) pairs = 1;
+    if (pairs > nblk) pairs = nblk;
+    hipLaunchKernelGGL(k_gru_cell_sb, dim3(2 * pairs, n_nets), dim3(512), 0, (hipStream_t)stream, (int)B, nblk, a);
     return (int)hipGetLastError();
 }
 

@@ -232,6 +232,8 @@ class MAPPO:
         self.use_graphs = bool(rt.get("use_graphs", True))
         ug = rt.get("update_group", "auto")    # mini-batches per autograd graph in train(): "auto" | int (see _update_group)
         self.update_group = "auto" if str(ug) == "auto" else int(ug)
+        if rt.get("gru_cell") is not None:   # "split_bf16" (default) | "fp32": the rollout's GRU cell kernel (ops.set_cell_mode; process-wide)
+            ops.set_cell_mode(str(rt.get("gru_cell")))
         self.update_group_max_GB = float(rt.get("update_group_max_GB", 200.0))
         # depth 0: nothing reads buffer["{actor,critic}_historical_embedding"], so the rollout does not fill them (they stay zero;
         # the reference stores every tick's embedding regardless, DHGN/mappo_parallel.py:795-798).  true = record them anyway.
@@ -454,7 +456,10 @@ class _RolloutState:
     History (FCRA hops): the embeddings of the last ticks live in a RING of pair slots `ring[M][2]` (slot t % M holds tick t's actor
     [0] and critic [1] embedding, written there directly by the forward pass), and a hop is a reference to a slot -- nothing is
     shifted or copied per tick (rounds 1-2 copied three (N, P, E) tensors per tick).  The addresses a tick reads and writes depend
-    on t % M only, so the captured per-tick program is one hipGraph per phase (M = 3 at depth 3 with the shared-history quirk)."""
+    on t % M only, so the captured per-tick program is one hipGraph per phase (M = 3 at depth 3 with the shared-history quirk).
+    GRU state: two buffers per network, tick t reads [t % 2] and writes [(t + 1) % 2] -- the split-bf16 cell (ops.CELL_MODE) shares a
+    row tile between two workgroups and cannot update the state in place; `ha` / `hc` are the current state.  The tick program
+    therefore repeats with period lcm(M, 2)."""
 
     def __init__(self, agent, env):
         self.agent = agent
@@ -468,7 +473,7 @@ class _RolloutState:
                         o_adj_bits=torch.zeros((N, P, ops.adj_row_words(O)), dtype=torch.int32, device=dev))  # LiDAR rows, bit-packed
         self.o_state = z(N, O, 4)
         self.o_kvalid = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.ha, self.hc = z(L, N * P, H), z(L, N * P, H)
+        self.hbuf_a, self.hbuf_c = z(2, L, N * P, H), z(2, L, N * P, H)
         # the shared history list is a quirk of the DHGN agent's rollout; separate encoders keep their own histories
         self.quirk = bool(agent.reference_quirks and agent.actor.shared_net is agent.critic.shared_net)
         # quirk: the list is (.., a_{t-1}, c_{t-1}) for BOTH networks -- two entries per tick, so d hops reach ceil(d / 2) ticks back;
@@ -480,9 +485,18 @@ class _RolloutState:
         self.logp, self.v, self.raw = z(N, P), z(N, P), z(N, P)
         self.counter = torch.full((1,), int(agent.sample_rank) << 40, dtype=torch.int64, device=dev)  # position in the sampling stream (persists)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # scratch of ops.head_sample (left zero by every launch)
-        self.graphs = {}                                      # phase (t % M) -> captured tick program
+        self.period = self.M if self.M % 2 == 0 else 2 * self.M   # of the tick program's addresses: ring slot and state parity
+        self.graphs = {}                                      # phase (t % period) -> captured tick program
         # one encoder pass per tick for both networks (DHGN.forward_pair): they hold the same DHGN instance (:582-616)
         self.pair_forward = agent.actor.shared_net is agent.critic.shared_net
+
+    @property
+    def ha(self):   # the actor's current GRU state (what tick self.t reads)
+        return self.hbuf_a[self.t & 1]
+
+    @property
+    def hc(self):
+        return self.hbuf_c[self.t & 1]
 
     # the embeddings of the tick most recently computed (what the rollout records into the buffer)
     @property
@@ -498,7 +512,7 @@ class _RolloutState:
         return None if self.quirk else self.ring[:, 1]
 
     def reset(self, env):
-        for t in (self.ha, self.hc, self.ring):
+        for t in (self.hbuf_a, self.hbuf_c, self.ring):
             t.zero_()
         self.t = 0
         self.o_state.copy_(env.boundary_map.obstacle_agent)
@@ -525,6 +539,8 @@ class _RolloutState:
         slot = self.ring[self.t % self.M]                    # this tick's embeddings land here
         a_cur, c_cur = slot[0], slot[1]
         o = self._obs()
+        ha_cur, hc_cur = self.ha, self.hc
+        ha_new, hc_new = self.hbuf_a[(self.t + 1) & 1], self.hbuf_c[(self.t + 1) & 1]
         # every result lands directly in the static rollout storage (no copies behind the model)
         if self.pair_forward and not torch.is_grad_enabled():
             # one encoder pass for both networks (they hold the same DHGN instance), then the two GRU trunks and heads
@@ -532,14 +548,15 @@ class _RolloutState:
                                                    hops_a, hops_c, o["o_kvalid"], 1, slot)
             a_emb, c_emb = emb[0], emb[1]
             if ag.actor.use_rnn and ag.critic.use_rnn:
-                # the two GRU trunks layer by layer, actor's and critic's cell in one launch; hidden states updated in place
+                # the two GRU trunks layer by layer, actor's and critic's cell in one launch; the new states land in the other buffers
                 E = a_emb.shape[-1]
-                fa, fc = ops.gru_step_multi([a_emb.reshape(-1, E), c_emb.reshape(-1, E)], [self.ha, self.hc], [ag.actor.GRU, ag.critic.GRU])
+                fa, fc = ops.gru_step_multi([a_emb.reshape(-1, E), c_emb.reshape(-1, E)], [ha_cur, hc_cur], [ag.actor.GRU, ag.critic.GRU],
+                                            hiddens_out=[ha_new, hc_new])
                 feat_a, feat_c = fa.reshape(self.N, self.P, -1), fc.reshape(self.N, self.P, -1)
-                ha, hc = self.ha, self.hc
+                ha, hc = ha_new, hc_new
             else:
-                feat_a, ha = ag.actor._rollout_features(a_emb, self.ha, True)
-                feat_c, hc = ag.critic._rollout_features(c_emb, self.hc, True)
+                feat_a, ha = ag.actor._rollout_features(a_emb, ha_cur, True)
+                feat_c, hc = ag.critic._rollout_features(c_emb, hc_cur, True)
             v = ag.critic.head(feat_c, out=self.v)            # the value lands in the static storage
             w_a = ag.actor.head_weight() if forced_actions is None else None
             feat_a = feat_a.contiguous()
@@ -550,17 +567,17 @@ class _RolloutState:
             else:
                 prob = torch.softmax(ag.actor.head(feat_a), dim=-1)
         else:
-            prob, ha, a_emb = ag.actor(o, hops_a, self.ha, 0, inplace_hidden=True, emb_out=a_cur)
-            v, hc, c_emb = ag.critic(o, hops_c, self.hc, 0, rollout=True, inplace_hidden=True, emb_out=c_cur)
+            prob, ha, a_emb = ag.actor(o, hops_a, ha_cur, 0, inplace_hidden=True, emb_out=a_cur)
+            v, hc, c_emb = ag.critic(o, hops_c, hc_cur, 0, rollout=True, inplace_hidden=True, emb_out=c_cur)
         if forced_actions is not None:
             self.a_n.copy_(forced_actions.to(torch.int32))
             self.logp.copy_(torch.distributions.Categorical(probs=prob).log_prob(forced_actions))
         elif prob is not None:
             ops.categorical_sample(prob, ag.sample_seed, 0, counter=self.counter, out=(self.a_n, self.logp))
-        if ha is not self.ha:
-            self.ha.copy_(ha)
-        if hc is not self.hc:
-            self.hc.copy_(hc)
+        if ha is not ha_new:       # paths that return a fresh state or updated the current one in place
+            ha_new.copy_(ha)
+        if hc is not hc_new:
+            hc_new.copy_(hc)
         if a_emb.data_ptr() != a_cur.data_ptr():
             a_cur.copy_(a_emb)
         if c_emb.data_ptr() != c_cur.data_ptr():
@@ -586,7 +603,7 @@ class _RolloutState:
         self.v.copy_(v.reshape(self.N, self.P))
 
     def replay_policy_step(self):
-        phase = self.t % self.M
+        phase = self.t % self.period
         g = self.graphs.get(phase)
         if g is None:
             g = self.graphs[phase] = self._capture()
@@ -596,7 +613,7 @@ class _RolloutState:
     def _capture(self):
         """Records the tick program of the current phase once.  The warm-up runs mutate the rollout state, so it is saved and
         restored."""
-        live = (self.ha, self.hc, self.ring, self.counter, self.a_n, self.logp, self.v)
+        live = (self.hbuf_a, self.hbuf_c, self.ring, self.counter, self.a_n, self.logp, self.v)
         keep = [t.clone() for t in live]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

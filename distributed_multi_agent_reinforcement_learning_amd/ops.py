@@ -15,7 +15,7 @@ ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -60,6 +60,7 @@ def load_library():
         L.gru_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]
         L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         L.gru_cell_fwd_multi.argtypes = [i32, vp, i32, i32, vp]
+        L.gru_cell_split_fwd_multi.argtypes = [i32, vp, i32, i32, vp]
         L.gru_seq_fwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_bwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_save_elems.argtypes = [i32, i32]
@@ -1073,25 +1074,43 @@ class GruCellNet(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "h_prev", "w_ih", "w_hh", "b_ih", "b_hh", "h_out")]
 
 
-def gru_step_multi(xs, hiddens, modules):
+# The rollout's GRU cells: "fp32" = v_mfma_f32_16x16x4_f32 (k_gru_cell), "split_bf16" = the same fp32 arithmetic from exact three-way
+# bf16 splits of the operands on v_mfma_f32_16x16x32_bf16 (k_gru_cell_sb, include/mappo_ops.h gru_cell_split_fwd_multi): same
+# results to fp32 rounding, 2.67 x the matrix rate.  `runtime.gru_cell` (MAPPO.__init__) or set_cell_mode().
+CELL_MODE = os.environ.get("MAPPO_GRU_CELL", "split_bf16")
+
+
+def set_cell_mode(mode):
+    global CELL_MODE
+    if mode not in ("fp32", "split_bf16"):
+        raise ValueError(f"runtime.gru_cell={mode!r}: 'fp32' or 'split_bf16'")
+    CELL_MODE = mode
+
+
+def gru_step_multi(xs, hiddens, modules, hiddens_out=None):
     """One rollout step of several independent GRU modules of one shape (actor and critic) without autograd: layer by layer, the
-    cells of all modules in ONE launch (gru_cell_fwd_multi); each module's hidden state (num_layers, B, 128) is updated IN PLACE
-    (every 16-row tile is read before it is written by the one workgroup that owns it).  xs: (B, 128) each.  Returns the top
-    layer's output per module (views of the hidden states).  Other shapes: ops.gru per module."""
+    cells of all modules in ONE launch.  xs: (B, 128) each; hiddens: per module (num_layers, B, 128).  hiddens_out None: each state
+    is updated IN PLACE (gru_cell_fwd_multi: every 16-row tile is read before it is written by the one workgroup that owns it).
+    hiddens_out given (same shapes, other storage): the new state is written there and `hiddens` is left as it was -- the form
+    the split-bf16 cell needs (CELL_MODE; two workgroups share a row tile).  Returns the top layer's output per module (views of the
+    new states).  Other shapes: ops.gru per module."""
     n = len(xs)
     B = xs[0].shape[0]
+    outs_h = hiddens if hiddens_out is None else hiddens_out
     ok = (not torch.is_grad_enabled() and n <= 4 and B >= FUSED_CELL_MIN_ROWS and all(x.shape == (B, 128) and x.is_cuda for x in xs)
-          and all(h.is_contiguous() and h.shape[1:] == (B, 128) for h in hiddens)
+          and all(h.is_contiguous() and h.shape[1:] == (B, 128) for h in list(hiddens) + list(outs_h))
           and all(m.num_layers == modules[0].num_layers and m.weight_hh_l0.shape == (384, 128) and m.weight_ih_l0.shape == (384, 128) for m in modules))
     if not ok:
         outs = []
-        for x, h, m in zip(xs, hiddens, modules):
-            out, hn = gru(x.unsqueeze(0), h, m, inplace_hidden=True)
-            if hn is not h:
-                h.copy_(hn)          # the per-step path returns a fresh state: keep the in-place contract
-            outs.append(out.squeeze(0))
+        for x, h, ho, m in zip(xs, hiddens, outs_h, modules):
+            out, hn = gru(x.unsqueeze(0), h, m, inplace_hidden=hiddens_out is None)
+            if hn is not ho:
+                ho.copy_(hn)          # the per-step path returns a fresh state: keep the contract of this function
+            outs.append(ho[-1])
         return outs
     L = load_library()
+    split = CELL_MODE == "split_bf16" and hiddens_out is not None
+    fn, what = (L.gru_cell_split_fwd_multi, "gru_cell_split_fwd_multi") if split else (L.gru_cell_fwd_multi, "gru_cell_fwd_multi")
     inps = [x.contiguous() for x in xs]
     for layer in range(modules[0].num_layers):
         arr = (GruCellNet * n)()
@@ -1099,11 +1118,11 @@ def gru_step_multi(xs, hiddens, modules):
         for k, m in enumerate(modules):
             ws = [getattr(m, f"{nm}_l{layer}").detach().contiguous() for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
             a = arr[k]
-            a.x, a.h_prev, a.h_out = inps[k].data_ptr(), hiddens[k][layer].data_ptr(), hiddens[k][layer].data_ptr()
+            a.x, a.h_prev, a.h_out = inps[k].data_ptr(), hiddens[k][layer].data_ptr(), outs_h[k][layer].data_ptr()
             a.w_ih, a.w_hh, a.b_ih, a.b_hh = (w.data_ptr() for w in ws)
             keep.append(ws)
-        _check(L.gru_cell_fwd_multi(n, C.cast(arr, C.c_void_p), B, 128, _stream()), "gru_cell_fwd_multi")
-        inps = [hiddens[k][layer] for k in range(n)]
+        _check(fn(n, C.cast(arr, C.c_void_p), B, 128, _stream()), what)
+        inps = [outs_h[k][layer] for k in range(n)]
     return inps
 
 

@@ -231,6 +231,12 @@ int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, cons
  * in gru_cell_fwd (n_nets <= MO_GRU_CELL_MAX_NETS).  The persistent workgroups (one per CU) are divided between the cells. */
 typedef struct mo_gru_cell_net { const float *x, *h_prev, *w_ih, *w_hh, *b_ih, *b_hh; float *h_out; } mo_gru_cell_net;
 int gru_cell_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, int32_t H, void *stream);
+/* The same cells in fp32 ARITHMETIC ON THE bf16 MATRIX PIPE: every fp32 operand is split exactly into three bf16 pieces
+ * (x = x1 + x2 + x3) and a product is the six piece products with i + j <= 4 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation --
+ * the dropped terms are below one fp32 rounding of the product; inputs, outputs and the state stay fp32 and the error against f64
+ * equals the fp32-MFMA kernel's (csrc/mappo_ops.hip k_gru_cell_sb).  Same records and results to fp32 rounding as
+ * gru_cell_fwd_multi, EXCEPT that h_out must not alias h_prev or x (two workgroups share a row tile). */
+int gru_cell_split_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, int32_t H, void *stream);
 
 /*
  * PPO clipped-surrogate policy loss and clipped value loss of one mini-batch with their gradients

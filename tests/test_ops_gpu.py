@@ -727,6 +727,49 @@ def test_gru_multi_equals_separate_calls(T, n, P, agents):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B", [32768, 4096, 1030, 17])
+def test_split_bf16_cell_is_as_accurate_as_the_fp32_cell(B):
+    """gru_cell_split_fwd_multi (k_gru_cell_sb): the rollout's GRU step from exact three-way bf16 splits of the fp32 operands, six bf16
+    MFMAs per product, fp32 accumulation.  Its error against an f64 torch.nn.GRU is the fp32-MFMA kernel's (a few 1e-7: summation
+    order), for two layers, both networks in one launch, row counts with a ragged last tile; the states it reads are left untouched
+    and an in-place call is refused."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(B)
+    mods = [torch.nn.GRU(128, 128, 2).cuda() for _ in range(2)]
+    xs = [torch.randn(B, 128, device="cuda") for _ in range(2)]
+    h0 = [torch.randn(2, B, 128, device="cuda") * 0.7 for _ in range(2)]
+    keep = [h.clone() for h in h0]
+    errs = {}
+    old = ops.CELL_MODE
+    try:
+        with torch.no_grad():
+            ref = []
+            for x, h, m in zip(xs, h0, mods):
+                m64 = torch.nn.GRU(128, 128, 2).cuda().double()
+                m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+                ref.append(m64(x.double().unsqueeze(0), h.double())[1])
+            for mode in ("fp32", "split_bf16"):
+                ops.set_cell_mode(mode)
+                outs = [torch.full_like(h, float("nan")) for h in h0]
+                top = ops.gru_step_multi(xs, h0, mods, hiddens_out=outs)
+                errs[mode] = max(float((o.double() - r).abs().max()) for o, r in zip(outs, ref))
+                assert all(t.data_ptr() == o[-1].data_ptr() for t, o in zip(top, outs))
+                assert all(torch.equal(h, k) for h, k in zip(h0, keep))
+            if B >= ops.FUSED_CELL_MIN_ROWS:
+                ops.set_cell_mode("split_bf16")
+                L = ops.load_library()
+                import ctypes as C
+                arr = (ops.GruCellNet * 1)()
+                m = mods[0]
+                arr[0].x, arr[0].h_prev, arr[0].h_out = xs[0].data_ptr(), h0[0][0].data_ptr(), h0[0][0].data_ptr()
+                arr[0].w_ih, arr[0].w_hh, arr[0].b_ih, arr[0].b_hh = (getattr(m, n).data_ptr() for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"))
+                assert L.gru_cell_split_fwd_multi(1, C.cast(arr, C.c_void_p), B, 128, None) != 0      # in place: refused
+    finally:
+        ops.set_cell_mode(old)
+    assert errs["fp32"] < 3e-6 and errs["split_bf16"] < 3e-6, errs
+    assert errs["split_bf16"] <= 2.0 * errs["fp32"] + 2e-7, errs
+
+
 def test_gru_multi_grouped_ragged_equals_separate_calls():
     """ops.gru_multi(grouped=True): the recurrences of several mini-batches' actor and critic layers -- different numbers of
     sequences, two of the inputs sharing one module's weights -- in one launch per layer and direction: outputs and every
