@@ -1379,6 +1379,92 @@ __global__ __launch_bounds__(512) void k_gru_cell_sb(int B, int nblk, GruCellNet
 #undef SBC_STAGE
 }
 
+// ---- Y = act(X W^T + b [+ C]) for 128 outputs, fp32 arithmetic on the bf16 matrix pipe (k_sb_gemm_n128) ------------------------
+// The rollout's Linear layers (DHGN AGG / semantic / FCRA layers, reference DHGN/mappo_parallel.py:148-233: 3e4-2e5 rows against a
+// 128 x {128, 256, 384} weight) on the exact three-way bf16 split of k_gru_cell_sb.  Persistent workgroups; wave w keeps output
+// units 16 w .. 16 w + 15 of W as A-operands (12 registers per 32 inputs, split once); 32 rows per iteration stream through a
+// double-buffered LDS image: a wave stages (chunk, half) blocks -- lane (gq, j) loads the 8 inputs 32 c + 8 gq .. of row j (16 rows
+// x 128 contiguous bytes per instruction), splits them and writes one 16-byte word per piece, which IS lane (j, gq)'s B-operand.
+// The result tile has a lane own four consecutive outputs of one row: bias, the optional addend (may be Y itself: beta = 1) and
+// ReLU in registers, one 16-byte store.  X, C and Y may be column blocks of wider matrices (row strides).
+template <int KC>   // inputs / 32
+__global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__restrict__ X, int64_t ldx, const float *__restrict__ W, int64_t ldw,
+                                                      const float *__restrict__ bias, const float *addend, int64_t lda, float *Y, int64_t ldy, int relu) {
+    extern __shared__ uint4 sbg_tile[];                 // [buffer][piece][chunk][row half][lane]
+    constexpr int IMG = 3 * KC * 2 * 64, UPW = KC / 4;  // uint4 per image; (chunk, half) blocks staged per wave and iteration
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, gq = l >> 4;
+    uint4 wg[KC][3];
+    {
+        const float *rw = W + (size_t)(16 * w + i) * ldw + 8 * gq;
+#pragma unroll
+        for (int c = 0; c < KC; c++) sb_split8(*(const float4 *)(rw + 32 * c), *(const float4 *)(rw + 32 * c + 4), wg[c]);
+    }
+    const float4 b4 = bias ? *(const float4 *)(bias + 16 * w + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t n_it = (R + 31) / 32;
+    float4 pf[UPW][2];
+    auto fetch = [&](int64_t it) {
+#pragma unroll
+        for (int n = 0; n < UPW; n++) {
+            const int blk = w * UPW + n, c = blk >> 1, rt = blk & 1;      // this wave's n-th (chunk, half) block
+            const int64_t row = it * 32 + rt * 16 + i;
+            pf[n][0] = pf[n][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < R) {
+                const float *src = X + row * ldx + 32 * c + 8 * gq;
+                pf[n][0] = *(const float4 *)src;
+                pf[n][1] = *(const float4 *)(src + 4);
+            }
+        }
+    };
+    auto stage = [&](uint4 *img) {
+#pragma unroll
+        for (int n = 0; n < UPW; n++) {
+            const int blk = w * UPW + n;
+            uint4 p_[3];
+            sb_split8(pf[n][0], pf[n][1], p_);
+#pragma unroll
+            for (int p = 0; p < 3; p++) img[(p * KC * 2 + blk) * 64 + l] = p_[p];
+        }
+    };
+    int64_t it = blockIdx.x;
+    if (it < n_it) { fetch(it); stage(sbg_tile); }
+    if (it + gridDim.x < n_it) fetch(it + gridDim.x);
+    lds_barrier();
+    int cur = 0;
+    for (; it < n_it; it += gridDim.x) {
+        const uint4 *tb = sbg_tile + cur * IMG + l;
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < KC; c++) {
+            uint4 b0[3], b1[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) { b0[p] = tb[(p * KC * 2 + 2 * c) * 64]; b1[p] = tb[(p * KC * 2 + 2 * c + 1) * 64]; }
+#define SBG_MMA(pi, pj)                                                                                                                       \
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[c][pi]), __builtin_bit_cast(bf16x8, b0[pj]), acc[0], 0, 0, 0); \
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[c][pi]), __builtin_bit_cast(bf16x8, b1[pj]), acc[1], 0, 0, 0);
+            SBG_MMA(2, 0) SBG_MMA(0, 2) SBG_MMA(1, 1) SBG_MMA(1, 0) SBG_MMA(0, 1) SBG_MMA(0, 0)
+#undef SBG_MMA
+        }
+        if (it + gridDim.x < n_it) stage(sbg_tile + (cur ^ 1) * IMG);          // the rows fetched one iteration ago -> the other image
+        if (it + 2 * (int64_t)gridDim.x < n_it) fetch(it + 2 * (int64_t)gridDim.x);
+        // D tile: lane (i, gq), register q -> output 16 w + 4 gq + q of row i of the half
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            const int64_t row = it * 32 + rt * 16 + i;
+            if (row < R) {
+                float4 v = make_float4(acc[rt][0] + b4.x, acc[rt][1] + b4.y, acc[rt][2] + b4.z, acc[rt][3] + b4.w);
+                if (addend) {
+                    const float4 a4 = *(const float4 *)(addend + row * lda + 16 * w + 4 * gq);
+                    v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *(float4 *)(Y + row * ldy + 16 * w + 4 * gq) = v;
+            }
+        }
+        lds_barrier();
+        cur ^= 1;
+    }
+}
+
 // ---- the sequence kernels: TRANSPOSED tiles ------------------------------------------------------------------------------------
 // A = weights, B = the h / dgh tile, so the MFMA result is gate^T: a lane owns FOUR CONSECUTIVE hidden units of ONE batch row
 // (rounds 1-2 computed gate[row][unit] tiles: one unit of four rows per lane, every global access a scalar in its own 64-byte
@@ -2103,6 +2189,24 @@ int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int
 
 }  // namespace
 
+template <int KC>
+int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
+                   float *Y, int64_t ldy, int relu, hipStream_t st) {
+    constexpr int lds = 2 * 3 * KC * 2 * 64 * 16;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_sb_gemm_n128<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int64_t n_it = (R + 31) / 32;
+    const int grid = n_it < cus ? (int)n_it : cus;
+    hipLaunchKernelGGL((k_sb_gemm_n128<KC>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu);
+    return (int)hipGetLastError();
+}
+
 extern "C" {
 
 int dhgn_msg_agg_fwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, const float *p, int64_t p_rs, const float *q,
@@ -2385,6 +2489,22 @@ int gru_cell_split_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_
     if (pairs > nblk) pairs = nblk;
     hipLaunchKernelGGL(k_gru_cell_sb, dim3(2 * pairs, n_nets), dim3(512), 0, (hipStream_t)stream, (int)B, nblk, a);
     return (int)hipGetLastError();
+}
+
+int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *addend,
+                 int64_t lda, float *Y, int64_t ldy, void *stream) {
+    if (R < 0 || !X || !W || !Y || ldx < K || ldw < K || ldy < 128 || (addend && lda < 128)) return MO_ERR_BAD_ARG;
+    if ((ldx & 3) || (ldw & 3) || (ldy & 3) || (lda & 3) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)addend & 15) ||
+        ((uintptr_t)bias & 15))
+        return MO_ERR_BAD_ARG;
+    if (R == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (K) {
+        case 128: return launch_sb_gemm<4>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+        case 256: return launch_sb_gemm<8>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+        case 384: return launch_sb_gemm<12>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+    }
+    return MO_ERR_BAD_ARG;
 }
 
 int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,

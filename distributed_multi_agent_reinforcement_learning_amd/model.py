@@ -151,14 +151,21 @@ class DHGN(nn.Module):
         m3 = ops.msg_agg3_pair(p, e, o, adj_p, adj_e, adj_o, M[0].weight, M[0].bias, M[1].weight, M[1].bias, M[2].weight, M[2].bias,
                                o_kvalid, q_div, pos=(Ws[:, :ind], self.semantic_layer.bias, h0) if fused_pos else None)   # (2, R, P, 3, E)
         agg0 = self.AGG_layers["AGG_vertex_0"]
-        emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)
+        m3_2d = m3.view(-1, E)
+        if ops.linear128_ok(m3_2d, agg0.weight):     # the rollout's Linear layers on the split-bf16 kernel (ops.CELL_MODE)
+            emb = ops.linear128(m3_2d, agg0.weight, agg0.bias, relu=True).view(m3.shape)
+        else:
+            emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)
         if not fused_pos:
             torch.addmm(self.semantic_layer.bias, p.reshape(R * P, ind), Ws[:, :ind].t(), out=h0_2d[:R * P])
             h0_2d[R * P:].copy_(h0_2d[:R * P])
-        if d:   # h0 is the right half of the first hop's operand: accumulate into it in place (beta = 1, strided output)
-            ops.gemm_nt(emb.view(2 * R * P, 3 * E), Ws[:, ind:], None, False, out=h0_2d, addend=h0_2d)
+        emb_2d, Wse = emb.view(2 * R * P, 3 * E), Ws[:, ind:]
+        if ops.linear128_ok(emb_2d, Wse, h0_2d, h0_2d):
+            ops.linear128(emb_2d, Wse, None, False, out=h0_2d, addend=h0_2d)
+        elif d:   # h0 is the right half of the first hop's operand: accumulate into it in place (beta = 1, strided output)
+            ops.gemm_nt(emb_2d, Wse, None, False, out=h0_2d, addend=h0_2d)
         else:
-            h0_2d.addmm_(emb.view(2 * R * P, 3 * E), Ws[:, ind:].t())
+            h0_2d.addmm_(emb_2d, Wse.t())
         if d == 0:
             return h0
         h = h0
@@ -167,15 +174,23 @@ class DHGN(nn.Module):
             # relu((abar @ hist) W^T + b) evaluated as relu(abar @ (hist W^T) + b): in the reference's rollout both networks read
             # the same history list, so the GEMM runs once for the two of them; the two neighbour means, the bias
             # and the ReLU are one launch that writes the left half of the hop's operand
-            za = ops.linear(hist_a[k], aggk.weight)
-            zc = za if hist_c[k] is hist_a[k] or hist_c[k].data_ptr() == hist_a[k].data_ptr() else ops.linear(hist_c[k], aggk.weight)
+            def lin(z, W=aggk.weight):
+                if z.is_contiguous() and ops.linear128_ok(z.view(-1, E), W):
+                    return ops.linear128(z.view(-1, E), W).view(z.shape)
+                return ops.linear(z, W)
+            za = lin(hist_a[k])
+            zc = za if hist_c[k] is hist_a[k] or hist_c[k].data_ptr() == hist_a[k].data_ptr() else lin(hist_c[k])
             ops.fcra_mean(z_actor=za, z_critic=zc, adj=adj_p, bias=aggk.bias, relu=True, out=cats[k][..., :E])
             last = k == d - 1
             if not last:
                 h = cats[k + 1][..., E:]
             else:
                 h = out if out is not None else torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
-            ops.gemm_nt(cats[k].view(2 * R * P, 2 * E), fk.weight, fk.bias, True, out=ops.block2d(h))
+            cat_2d, h_2d = cats[k].view(2 * R * P, 2 * E), ops.block2d(h)
+            if ops.linear128_ok(cat_2d, fk.weight, h_2d):
+                ops.linear128(cat_2d, fk.weight, fk.bias, True, out=h_2d)
+            else:
+                ops.gemm_nt(cat_2d, fk.weight, fk.bias, True, out=h_2d)
         return h
 
 

@@ -15,7 +15,7 @@ ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -61,6 +61,7 @@ def load_library():
         L.gru_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         L.gru_cell_fwd_multi.argtypes = [i32, vp, i32, i32, vp]
         L.gru_cell_split_fwd_multi.argtypes = [i32, vp, i32, i32, vp]
+        L.sb_gemm_n128.argtypes = [i64, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp, i64, vp]
         L.gru_seq_fwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_bwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_save_elems.argtypes = [i32, i32]
@@ -1085,6 +1086,31 @@ def set_cell_mode(mode):
     if mode not in ("fp32", "split_bf16"):
         raise ValueError(f"runtime.gru_cell={mode!r}: 'fp32' or 'split_bf16'")
     CELL_MODE = mode
+
+
+def linear128_ok(x, W, out=None, addend=None):
+    """shapes and strides sb_gemm_n128 covers: 128 outputs, 128 / 256 / 384 inputs, fp32, rows 16-byte aligned"""
+    if CELL_MODE != "split_bf16" or torch.is_grad_enabled() or not x.is_cuda or W.shape[0] != 128 or W.shape[1] not in (128, 256, 384):
+        return False
+    for t in (x, W) + ((out,) if out is not None else ()) + ((addend,) if addend is not None else ()):
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+            return False
+    return x.shape[1] == W.shape[1]
+
+
+def linear128(x, W, bias=None, relu=False, out=None, addend=None):
+    """out = act(x W^T + bias + addend) for 2-D x (rows, K), W (128, K), out / addend (rows, 128), any row strides, in fp32
+    arithmetic on the bf16 matrix pipe (exact three-way operand splits, include/mappo_ops.h sb_gemm_n128).  The rollout's Linear
+    layers; no autograd.  addend may be out (accumulate in place)."""
+    L = load_library()
+    R, K = x.shape
+    W = W.detach()
+    if out is None:
+        out = torch.empty((R, 128), dtype=torch.float32, device=x.device)
+    b = bias.detach() if bias is not None else None
+    _check(L.sb_gemm_n128(R, K, _ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), int(bool(relu)), _ptr(addend),
+                          addend.stride(0) if addend is not None else 0, _ptr(out), out.stride(0), _stream()), "sb_gemm_n128")
+    return out
 
 
 def gru_step_multi(xs, hiddens, modules, hiddens_out=None):

@@ -237,6 +237,12 @@ int gru_cell_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, i
  * equals the fp32-MFMA kernel's (csrc/mappo_ops.hip k_gru_cell_sb).  Same records and results to fp32 rounding as
  * gru_cell_fwd_multi, EXCEPT that h_out must not alias h_prev or x (two workgroups share a row tile). */
 int gru_cell_split_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_t B, int32_t H, void *stream);
+/* Y[R][128] = act(X[R][K] W[128][K]^T + bias [+ C]) in the same split arithmetic (fp32 in, fp32 out, fp32 accumulation; K in {128, 256,
+ * 384}): the rollout's Linear layers (torch.nn.Linear of DHGN/mappo_parallel.py:148-233).  bias, C may be NULL; C may be Y (accumulate in
+ * place); relu != 0 applies max(., 0) last.  ldx, ldw, ldc, ldy: row strides in floats (multiples of 4: X, C, Y may be column blocks of
+ * wider matrices); all pointers 16-byte aligned. */
+int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *C,
+                 int64_t ldc, float *Y, int64_t ldy, void *stream);
 
 /*
  * PPO clipped-surrogate policy loss and clipped value loss of one mini-batch with their gradients

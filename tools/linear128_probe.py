@@ -1,0 +1,35 @@
+"""The rollout's Linear layers: the split-bf16 kernel (ops.linear128) beside the library GEMM at the tick's shapes.
+python tools/linear128_probe.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_multi_agent_reinforcement_learning_amd import ops  # noqa: E402
+
+dev = "cuda"
+ops.set_cell_mode("split_bf16")
+
+
+def timed(fn, n=50):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+with torch.no_grad():
+    for name, R, K, relu, bias, acc in (("AGG_vertex (3 relations x 2 nets)", 196608, 128, True, True, False), ("semantic layer (beta = 1)", 65536, 384, False, False, True),
+                                        ("FCRA AGG", 32768, 128, False, False, False), ("FCRA layer", 65536, 256, True, True, False)):
+        x = torch.randn(R, K, device=dev); W = torch.randn(128, K, device=dev) * 0.1; b = torch.randn(128, device=dev) if bias else None
+        out = torch.randn(R, 128, device=dev)
+        t_s = timed(lambda: ops.linear128(x, W, b, relu, out=out, addend=out if acc else None))
+        t_l = timed(lambda: ops.gemm_nt(x, W, b, relu, out=out, addend=out if acc else None))
+        gb = (R * K + R * 128 * (2 if acc else 1)) * 4
+        print(f"{name:36s} {R:7d} x {K:3d}: split {t_s:6.1f} us ({2.0 * R * K * 128 / t_s / 1e6:6.1f} TFLOP/s, {gb / t_s / 1e3:5.0f} GB/s)   library {t_l:6.1f} us")
