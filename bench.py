@@ -140,9 +140,18 @@ def measure_compute_kernels(trainer, cfg):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3
 
-    def entry(kernel, fl, t, bound="mfma", **kw):
-        return dict(bound=bound, kernel=kernel, achieved=round(fl / t / 1e12, 2), peak=FP32_PEAK_TF, unit="TFLOP/s",
-                    frac=round(fl / t / (FP32_PEAK_TF * 1e12), 4), us_per_launch=round(t * 1e6, 1), **kw)
+    split = ops.MATMUL_MODE == "split_bf16"
+    SPLIT_PEAK_TF = 2500.0 / 6.0   # fp32-equivalent rate of six bf16 MFMAs per product at the dense bf16 peak
+
+    def entry(kernel, fl, t, bound="mfma", split_kernel=False, **kw):
+        """algorithmic fp32 flops over time; `peak` is the pipe the kernel runs on: the fp32 MFMA peak, or for the split-bf16 kernels
+        the bf16 peak / 6 (frac_of_fp32_mfma_peak keeps the figure the fp32 kernels are priced by: it may exceed 1)"""
+        peak = SPLIT_PEAK_TF if split_kernel else FP32_PEAK_TF
+        e = dict(bound=bound, kernel=kernel, achieved=round(fl / t / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s",
+                 frac=round(fl / t / (peak * 1e12), 4), us_per_launch=round(t * 1e6, 1), **kw)
+        if split_kernel:
+            e["frac_of_fp32_mfma_peak"] = round(fl / t / (FP32_PEAK_TF * 1e12), 4)
+        return e
     out = {}
     if E == 128 and cfg.algo.rnn_hidden_dim == 128:
         B = mb * P
@@ -172,14 +181,23 @@ def measure_compute_kernels(trainer, cfg):
         Kr = mb * T * P  # rows of one mini-batch: the weight gradient of a GRU projection reduces over all of them
         ga = torch.randn(Kr, 384, device=dev); xa = torch.randn(Kr, 128, device=dev)
         t = timeit(lambda: ops.wgrad(ga, xa))
-        out["wgrad"] = entry("k_wgrad<3,1> + reduce (dW_ih [384][128] = dgi^T x over the mini-batch rows, split-K)", 2.0 * Kr * 384 * 128, t,
-                             rows=Kr, hbm_GBps=round((384 + 128) * 4.0 * Kr / t / 1e9, 1))
+        out["wgrad"] = entry(("k_sb_wgrad<3,1> (exact bf16 operand splits)" if ops.WGRAD_MODE == "split_bf16" else "k_wgrad<3,1>")
+                             + " + reduce (dW_ih [384][128] = dgi^T x over the mini-batch rows, split-K)", 2.0 * Kr * 384 * 128, t,
+                             split_kernel=ops.WGRAD_MODE == "split_bf16", rows=Kr, hbm_GBps=round((384 + 128) * 4.0 * Kr / t / 1e9, 1))
         del ga, xa
         Br = trainer.num_envs * P
         xr, hr, ho = torch.randn(Br, 128, device=dev), torch.randn(Br, 128, device=dev), torch.empty(Br, 128, device=dev)
         wi, wh, bi, bh = w, torch.randn(384, 128, device=dev) * 0.08, b, torch.zeros(384, device=dev)
-        t = timeit(lambda: L.gru_cell_fwd(Br, 128, ptr(xr), ptr(hr), ptr(wi), ptr(wh), ptr(bi), ptr(bh), ptr(ho), st), n=20)  # C ABI directly
-        out["gru_cell"] = entry("k_gru_cell (one rollout GRU layer step: both projections + gates, one launch)", 2.0 * Br * 128 * 768, t, rows=Br)
+        if ops.CELL_MODE == "split_bf16":   # what the tick launches: actor's and critic's cell of one layer, split-bf16 kernel, C ABI directly
+            arr = (ops.GruCellNet * 2)()
+            for a_ in arr:
+                a_.x, a_.h_prev, a_.h_out, a_.w_ih, a_.w_hh, a_.b_ih, a_.b_hh = (t_.data_ptr() for t_ in (xr, hr, ho, wi, wh, bi, bh))
+            t = timeit(lambda: L.gru_cell_split_fwd_multi(2, C.cast(arr, C.c_void_p), Br, 128, st), n=20)
+            out["gru_cell"] = entry("k_gru_cell_sb (one rollout GRU layer step of actor and critic: both projections + gates, one launch, exact bf16 "
+                                    "operand splits)", 2 * 2.0 * Br * 128 * 768, t, split_kernel=True, rows=2 * Br)
+        else:
+            t = timeit(lambda: L.gru_cell_fwd(Br, 128, ptr(xr), ptr(hr), ptr(wi), ptr(wh), ptr(bi), ptr(bh), ptr(ho), st), n=20)  # C ABI directly
+            out["gru_cell"] = entry("k_gru_cell (one rollout GRU layer step: both projections + gates, one launch)", 2.0 * Br * 128 * 768, t, rows=Br)
     # DHGN message + mean aggregation: the kernels never form the (rows, P, K, E) message, so flops of the reference formulation are
     # not a hardware figure for them; they are priced by the bytes they must move (inputs + the (rows, P, relations, E) output)
     R = mb * T
@@ -317,6 +335,11 @@ def self_launch(args, argv):
     return child.wait()
 
 
+def _matmul_mode():
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    return ops.MATMUL_MODE
+
+
 def run_config(name, args, with_roofline):
     """2 set-up iterations (graph capture, allocator growth: once per process) + W warm-up + exactly K timed iterations,
     bracketed by barrier + synchronize, MAX over ranks.  Returns the result dict (rank 0 fills the JSON from it)."""
@@ -369,7 +392,7 @@ def run_config(name, args, with_roofline):
                workload=f"{name}: pursuit_evasion_game {P} defenders, {W}x{H} map, {N} envs/GPU, T={T}, DHGN depth {cfg.algo.depth} + "
                         f"2-layer GRU actor/critic, rollout + PPO update",
                envs_per_gpu=N, episode_steps=T, mini_batch_size=tr.mini_batch_size, backend=(dist.get_backend() if world > 1 else None),
-               update_group=tr.agent.update_group, hbm_peak_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
+               update_group=tr.agent.update_group, hbm_peak_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1), matmul=_matmul_mode())
     # GEMM-shaped algorithmic work of one iteration (SURVEY 8d F_net without the message terms, which the kernels do not execute as
     # flops): per network and env-step; the rollout runs each network forward once, every epoch of the update forward + backward (3x)
     E_, H_, A_, d_ = cfg.algo.embedding_dim, cfg.algo.rnn_hidden_dim, cfg.env.action_dim, cfg.algo.depth
@@ -377,7 +400,8 @@ def run_config(name, args, with_roofline):
              + (cfg.algo.num_layers * 2 * (2 * P * E_ * 3 * H_) if cfg.algo.get("use_rnn", True) else 0) + 2 * P * H_ * A_)
     flops_iter = 2 * f_net * (1 + 3 * int(cfg.algo.epochs)) * N * T
     res["roofline_iteration"] = {"bound": "mfma", "what": "GEMM-shaped algorithmic flops of one iteration (both networks: rollout forward + update forward and "
-                                 "backward) over the measured iteration time", "flops_per_net_env_step": f_net, "flops_per_iteration": flops_iter,
+                                 "backward) over the measured iteration time, against the fp32 MFMA peak (the price of the fp32 formulation; with runtime.matmul: split_bf16 part of "
+                                 "the products runs on the bf16 pipe at up to 2.67 x that rate)", "flops_per_net_env_step": f_net, "flops_per_iteration": flops_iter,
                                  "achieved": round(flops_iter / (dt / args.steps) / 1e12, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": round(flops_iter / (dt / args.steps) / 1e12 / FP32_PEAK_TF, 4)}
     if with_roofline:
@@ -462,15 +486,28 @@ def main():
     from distributed_multi_agent_reinforcement_learning_amd.trainer import dist_env
     rank, local_rank, world = dist_env()
     main_res = run_config(args.config, args, with_roofline=True)
-    second = None
+    second = fp32_run = None
     if args.config == "cfg2" and not args.no_secondary:
         second = run_config("cfg3", args, with_roofline=False)
+        # the same headline configuration with every matrix product on the fp32 MFMA kernels / the BLAS library (runtime.matmul: fp32),
+        # for comparison: the default evaluates fp32 products from exact three-way bf16 operand splits
+        from distributed_multi_agent_reinforcement_learning_amd import ops as _ops
+        mode = _ops.MATMUL_MODE
+        if mode != "fp32":
+            _ops.set_matmul_mode("fp32")
+            try:
+                fp32_run = run_config("cfg2", args, with_roofline=False)
+            finally:
+                _ops.set_matmul_mode(mode)
     if rank == 0:
         out = {
             "metric": "env-steps/sec (whole node), pursuit-evasion 8-agent 4096-env", "value": main_res["value"],
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64 environment / f32 policy", "data": "synthetic (seeded random maps, random-init weights)",
+            "matmul": ("fp32 products from exact three-way bf16 splits of the fp32 operands (6 bf16 MFMAs per product, fp32 accumulation, fp32 storage; error "
+                       "against f64 = an fp32 GEMM's, tests/test_ops_gpu.py); configs.cfg2_fp32_mfma is the same run on fp32 MFMA / BLAS"
+                       if main_res["matmul"] == "split_bf16" else "fp32 MFMA kernels / BLAS library fp32 GEMMs"),
             "config": {"workload": main_res["workload"], "envs_per_gpu": main_res["envs_per_gpu"], "episode_steps": main_res["episode_steps"],
                        "mini_batch_size": main_res["mini_batch_size"], "update_group": main_res["update_group"],
                        "parallelism": f"dp{world} ({args.scaling} scaling: " + (f"{main_res['envs_per_gpu'] * world} environments in total, {main_res['envs_per_gpu']} per rank)"
@@ -484,6 +521,8 @@ def main():
         }
         if second is not None:
             out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "hbm_peak_GB", "workload", "roofline_iteration")}}
+        if fp32_run is not None:
+            out.setdefault("configs", {})["cfg2_fp32_mfma"] = {k: fp32_run[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "matmul")}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

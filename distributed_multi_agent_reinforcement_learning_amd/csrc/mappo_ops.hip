@@ -1379,27 +1379,29 @@ __global__ __launch_bounds__(512) void k_gru_cell_sb(int B, int nblk, GruCellNet
 #undef SBC_STAGE
 }
 
-// ---- Y = act(X W^T + b [+ C]) for 128 outputs, fp32 arithmetic on the bf16 matrix pipe (k_sb_gemm_n128) ------------------------
+// ---- Y = act(X W^T + b [+ C]) for 128 (384) outputs, fp32 arithmetic on the bf16 matrix pipe (k_sb_gemm_n128) ------------------
 // The rollout's Linear layers (DHGN AGG / semantic / FCRA layers, reference DHGN/mappo_parallel.py:148-233: 3e4-2e5 rows against a
-// 128 x {128, 256, 384} weight) on the exact three-way bf16 split of k_gru_cell_sb.  Persistent workgroups; wave w keeps output
-// units 16 w .. 16 w + 15 of W as A-operands (12 registers per 32 inputs, split once); 32 rows per iteration stream through a
+// 128 x {128, 256, 384} weight; and the update's GRU input projection, 384 x 128) on the exact three-way bf16 split of k_gru_cell_sb.
+// Persistent workgroups; wave w keeps output units 16 (w + 8 t) .. + 15 of W as A-operands (12 registers per 32 inputs and tile, split once); 32 rows per iteration stream through a
 // double-buffered LDS image: a wave stages (chunk, half) blocks -- lane (gq, j) loads the 8 inputs 32 c + 8 gq .. of row j (16 rows
 // x 128 contiguous bytes per instruction), splits them and writes one 16-byte word per piece, which IS lane (j, gq)'s B-operand.
 // The result tile has a lane own four consecutive outputs of one row: bias, the optional addend (may be Y itself: beta = 1) and
 // ReLU in registers, one 16-byte store.  X, C and Y may be column blocks of wider matrices (row strides).
-template <int KC>   // inputs / 32
+template <int KC, int NT>   // inputs / 32, outputs / 128
 __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__restrict__ X, int64_t ldx, const float *__restrict__ W, int64_t ldw,
                                                       const float *__restrict__ bias, const float *addend, int64_t lda, float *Y, int64_t ldy, int relu) {
     extern __shared__ uint4 sbg_tile[];                 // [buffer][piece][chunk][row half][lane]
     constexpr int IMG = 3 * KC * 2 * 64, UPW = KC / 4;  // uint4 per image; (chunk, half) blocks staged per wave and iteration
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, gq = l >> 4;
-    uint4 wg[KC][3];
-    {
-        const float *rw = W + (size_t)(16 * w + i) * ldw + 8 * gq;
+    uint4 wg[NT][KC][3];                                // output tiles w, w + 8, .. (16 outputs each)
+    float4 b4[NT];
 #pragma unroll
-        for (int c = 0; c < KC; c++) sb_split8(*(const float4 *)(rw + 32 * c), *(const float4 *)(rw + 32 * c + 4), wg[c]);
+    for (int t = 0; t < NT; t++) {
+        const float *rw = W + (size_t)(16 * (w + 8 * t) + i) * ldw + 8 * gq;
+#pragma unroll
+        for (int c = 0; c < KC; c++) sb_split8(*(const float4 *)(rw + 32 * c), *(const float4 *)(rw + 32 * c + 4), wg[t][c]);
+        b4[t] = bias ? *(const float4 *)(bias + 16 * (w + 8 * t) + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float4 b4 = bias ? *(const float4 *)(bias + 16 * w + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t n_it = (R + 31) / 32;
     float4 pf[UPW][2];
     auto fetch = [&](int64_t it) {
@@ -1432,32 +1434,40 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
     int cur = 0;
     for (; it < n_it; it += gridDim.x) {
         const uint4 *tb = sbg_tile + cur * IMG + l;
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t][0] = acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < KC; c++) {
             uint4 b0[3], b1[3];
 #pragma unroll
             for (int p = 0; p < 3; p++) { b0[p] = tb[(p * KC * 2 + 2 * c) * 64]; b1[p] = tb[(p * KC * 2 + 2 * c + 1) * 64]; }
-#define SBG_MMA(pi, pj)                                                                                                                       \
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[c][pi]), __builtin_bit_cast(bf16x8, b0[pj]), acc[0], 0, 0, 0); \
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[c][pi]), __builtin_bit_cast(bf16x8, b1[pj]), acc[1], 0, 0, 0);
+#define SBG_MMA(pi, pj)                                                                                                                             \
+            _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                                                          \
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b0[pj]), acc[t][0], 0, 0, 0); \
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b1[pj]), acc[t][1], 0, 0, 0); \
+            }
             SBG_MMA(2, 0) SBG_MMA(0, 2) SBG_MMA(1, 1) SBG_MMA(1, 0) SBG_MMA(0, 1) SBG_MMA(0, 0)
 #undef SBG_MMA
         }
         if (it + gridDim.x < n_it) stage(sbg_tile + (cur ^ 1) * IMG);          // the rows fetched one iteration ago -> the other image
         if (it + 2 * (int64_t)gridDim.x < n_it) fetch(it + 2 * (int64_t)gridDim.x);
-        // D tile: lane (i, gq), register q -> output 16 w + 4 gq + q of row i of the half
+        // D tile: lane (i, gq), register q -> output 16 (w + 8 t) + 4 gq + q of row i of the half
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
             const int64_t row = it * 32 + rt * 16 + i;
             if (row < R) {
-                float4 v = make_float4(acc[rt][0] + b4.x, acc[rt][1] + b4.y, acc[rt][2] + b4.z, acc[rt][3] + b4.w);
-                if (addend) {
-                    const float4 a4 = *(const float4 *)(addend + row * lda + 16 * w + 4 * gq);
-                    v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int col = 16 * (w + 8 * t) + 4 * gq;
+                    float4 v = make_float4(acc[t][rt][0] + b4[t].x, acc[t][rt][1] + b4[t].y, acc[t][rt][2] + b4[t].z, acc[t][rt][3] + b4[t].w);
+                    if (addend) {
+                        const float4 a4 = *(const float4 *)(addend + row * lda + col);
+                        v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                    }
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *(float4 *)(Y + row * ldy + col) = v;
                 }
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *(float4 *)(Y + row * ldy + 16 * w + 4 * gq) = v;
             }
         }
         lds_barrier();
@@ -1952,6 +1962,179 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float
     }
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// the six piece products of one 32 x 32 x 16 tile step, smallest first
+__device__ __forceinline__ f32x16 sb_mma6_32(const uint4 (&a)[3], const uint4 (&b)[3], f32x16 c) {
+#define SB_MMA(i, j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), c, 0, 0, 0);
+    SB_MMA(2, 0) SB_MMA(0, 2) SB_MMA(1, 1) SB_MMA(1, 0) SB_MMA(0, 1) SB_MMA(0, 0)
+#undef SB_MMA
+    return c;
+}
+
+// ---- weight gradient  C[M][N] = A^T B in the split arithmetic (k_sb_wgrad; A [K][M], B [K][N], K ~ 5e5 rows) ---------------------
+// One workgroup (8 waves, two per SIMD: one wave's splitting runs under the other's MFMAs) owns the WHOLE M x N output in its
+// accumulators and a contiguous range of the rows (split-K, partials reduced in a fixed order afterwards).  Rows arrive in chunks
+// of 16: a thread loads 4 consecutive rows x 4 features with 16-byte loads -- a wave reads 1 KB contiguous pieces of a row --,
+// splits them and writes, per feature and piece, its 4 rows as half of a 16-byte LDS word that holds 8 consecutive rows of one
+// feature: exactly the 8 contraction steps a lane feeds to v_mfma_f32_32x32x16_bf16 (lane (i, g): tile row/column i, steps
+// 8 g .. 8 g + 7), so an operand is one ds_read_b128 and the transposition K-major -> feature-major costs nothing.  Features
+// inside a 64-byte block are XOR-swizzled by (feature / 8) % 4 to spread the writes (lane stride 64 bytes) over the banks; readers
+// of 32 consecutive features stay conflict-free.  The LDS image is double-buffered (2 x 48 KB): chunk c + 1 is split and written
+// while chunk c is multiplied, one barrier per chunk; the raw rows of the next SB_DEPTH chunks are in flight in registers (128 KB
+// per CU: one chunk ahead left the HBM latency exposed, 3.4 us under load against a 2 us matrix phase).
+constexpr int SB_DEPTH = 4;
+
+template <int MT, int NT>
+struct SbWgCfg {
+    static constexpr int M = 128 * MT, N = 128 * NT, COLS = M + N, FQ = COLS / 4;
+    static constexpr int CR = 16, NO = 2;                // rows and row octets per chunk
+    static constexpr int WGM = MT >= NT ? 4 : 2;         // wave grid WGM x WGN over the output, TM x TN tiles of 32 x 32 per wave
+    static constexpr int WGN = 8 / WGM;
+    static constexpr int TM = M / 32 / WGM, TN = N / 32 / WGN;
+    static constexpr int UNITS = 2 * NO * FQ;            // (row octet, half, feature quad) load units per chunk: one per thread
+    static constexpr int IMG = 3 * NO * COLS;            // uint4 per LDS image
+    static constexpr int LDS_BYTES = 2 * IMG * 16;
+};
+
+// feature f's slot in the LDS image
+__device__ __forceinline__ int sb_swz(int f) { return (f & ~3) | ((f & 3) ^ ((f >> 3) & 3)); }
+template <int MT, int NT>
+__global__ __launch_bounds__(512) void k_sb_wgrad(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int64_t K,
+                                                  float *__restrict__ part) {
+    using C = SbWgCfg<MT, NT>;
+    extern __shared__ uint4 sb_lds[];                    // [buffer][piece][octet][feature slot] x 16 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    // loader role: thread -> (octet, half, feature quad)
+    const bool on = tid < C::UNITS;
+    const int rest = on ? tid / C::FQ : 0, col = 4 * (tid % C::FQ);
+    const int row_in_chunk = 4 * rest;                   // = 8 octet + 4 half
+    const float *src = (col < C::M ? A + col : B + (col - C::M)) + row_in_chunk * (col < C::M ? lda : ldb);
+    const int64_t ld = col < C::M ? lda : ldb;
+    const int slot2 = 2 * ((rest >> 1) * C::COLS + col) + (rest & 1), sx = (col >> 3) & 3;   // in 8-byte units
+    // multiplier role
+    const int wm = wave / C::WGN, wn = wave % C::WGN;
+    const int64_t chunks = K / C::CR;                    // full chunks; the K % 16 tail rows are the last workgroup's epilogue
+    const int64_t c_beg = chunks * blockIdx.x / gridDim.x, c_end = chunks * (blockIdx.x + 1) / gridDim.x;
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int a = 0; a < C::TM; a++)
+#pragma unroll
+        for (int b = 0; b < C::TN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    float4 raw[SB_DEPTH][4];
+    auto fetch = [&](float4 (&r)[4], int64_t c) {
+        if (!on || c >= c_end) return;
+        const float *p = src + c * C::CR * ld;
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = *(const float4 *)(p + j * ld);
+    };
+    // registers -> three bf16 pieces -> LDS image
+    auto stage = [&](const float4 (&r)[4], uint4 *img) {
+        if (!on) return;
+        uint2 *img2 = (uint2 *)img;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            uint32_t p[3][2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float x0 = t == 0 ? r[2 * q].x : t == 1 ? r[2 * q].y : t == 2 ? r[2 * q].z : r[2 * q].w;
+                const float x1 = t == 0 ? r[2 * q + 1].x : t == 1 ? r[2 * q + 1].y : t == 2 ? r[2 * q + 1].z : r[2 * q + 1].w;
+                sb_split2(x0, x1, p[0][q], p[1][q], p[2][q]);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++) img2[2 * s * C::NO * C::COLS + slot2 + 2 * (t ^ sx)] = make_uint2(p[s][0], p[s][1]);
+        }
+    };
+    auto multiply = [&](const uint4 *buf) {
+        const uint4 *img = buf + g * C::COLS;
+        constexpr int PS = C::NO * C::COLS;              // piece stride
+        if constexpr (C::TN <= C::TM) {                  // the narrower side's operands stay in registers across the other's tiles
+            uint4 b[C::TN][3];
+#pragma unroll
+            for (int nt = 0; nt < C::TN; nt++) {
+                const int f = sb_swz(C::M + 32 * (wn * C::TN + nt) + i);
+#pragma unroll
+                for (int s = 0; s < 3; s++) b[nt][s] = img[s * PS + f];
+            }
+#pragma unroll
+            for (int mt = 0; mt < C::TM; mt++) {
+                const int f = sb_swz(32 * (wm * C::TM + mt) + i);
+                uint4 a[3];
+#pragma unroll
+                for (int s = 0; s < 3; s++) a[s] = img[s * PS + f];
+#pragma unroll
+                for (int nt = 0; nt < C::TN; nt++) acc[mt][nt] = sb_mma6_32(a, b[nt], acc[mt][nt]);
+            }
+        } else {
+            uint4 a[C::TM][3];
+#pragma unroll
+            for (int mt = 0; mt < C::TM; mt++) {
+                const int f = sb_swz(32 * (wm * C::TM + mt) + i);
+#pragma unroll
+                for (int s = 0; s < 3; s++) a[mt][s] = img[s * PS + f];
+            }
+#pragma unroll
+            for (int nt = 0; nt < C::TN; nt++) {
+                const int f = sb_swz(C::M + 32 * (wn * C::TN + nt) + i);
+                uint4 b[3];
+#pragma unroll
+                for (int s = 0; s < 3; s++) b[s] = img[s * PS + f];
+#pragma unroll
+                for (int mt = 0; mt < C::TM; mt++) acc[mt][nt] = sb_mma6_32(a[mt], b, acc[mt][nt]);
+            }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < SB_DEPTH; d++) fetch(raw[d], c_beg + d);
+    if (c_beg < c_end) {
+        stage(raw[0], sb_lds);
+        fetch(raw[0], c_beg + SB_DEPTH);
+    }
+    lds_barrier();
+    // invariant at the top of step c: image (c - c_beg) % 2 holds chunk c; raw[(c + k - c_beg) % DEPTH] holds chunk c + k, k = 1 .. DEPTH
+    for (int64_t c = c_beg; c < c_end; c += SB_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SB_DEPTH; d++) {
+            const int64_t cc = c + d;
+            if (cc >= c_end) break;
+            uint4 *cur = sb_lds + (d & 1) * C::IMG, *nxt = sb_lds + ((d + 1) & 1) * C::IMG;   // SB_DEPTH is even: parity of d = parity of cc - c_beg
+            // the two waves of a SIMD (w and w + 4) run out of phase: one splits the next chunk while the other multiplies
+            if (wave < 4) {
+                if (cc + 1 < c_end) stage(raw[(d + 1) % SB_DEPTH], nxt);
+                fetch(raw[(d + 1) % SB_DEPTH], cc + 1 + SB_DEPTH);
+                multiply(cur);
+            } else {
+                multiply(cur);
+                if (cc + 1 < c_end) stage(raw[(d + 1) % SB_DEPTH], nxt);
+                fetch(raw[(d + 1) % SB_DEPTH], cc + 1 + SB_DEPTH);
+            }
+            lds_barrier();
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && (K % C::CR)) {     // the K % 16 tail rows, zero-filled
+        float4 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            r[j] = (on && chunks * C::CR + row_in_chunk + j < K) ? *(const float4 *)(src + (chunks * C::CR + j) * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+        stage(r, sb_lds);
+        lds_barrier();
+        multiply(sb_lds);
+    }
+    // D tile (32 x 32): lane (i, g), register r -> row 8 (r / 4) + 4 g + r % 4 (the A operand's tile row: an M index), column i
+    float *po = part + (size_t)blockIdx.x * C::M * C::N + (size_t)(32 * wm * C::TM + 4 * g) * C::N + 32 * wn * C::TN + i;
+#pragma unroll
+    for (int mt = 0; mt < C::TM; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+#pragma unroll
+            for (int nt = 0; nt < C::TN; nt++) po[(size_t)(32 * mt + 8 * (r / 4) + (r % 4)) * C::N + 32 * nt] = acc[mt][nt][r];
+}
+
+
 // ---- neighbour mean of the fixed-depth recursive aggregation (DHGN.fcra, DHGN/mappo_parallel.py:204-233) ----------------------
 // out[r][i][:] = act( sum_j abar_ij z[r][j][:] + bias ),  abar = adj / max(sum_j |adj|, 1e-12)  (F.normalize(adj, p=1, dim=-1))
 // for the actor, abar = 1 / P for the critic (normalize(ones_like(adj))): the reference's torch.matmul(abar, hist) -- a batched
@@ -2189,13 +2372,13 @@ int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int
 
 }  // namespace
 
-template <int KC>
+template <int KC, int NT>
 int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
                    float *Y, int64_t ldy, int relu, hipStream_t st) {
     constexpr int lds = 2 * 3 * KC * 2 * 64 * 16;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_sb_gemm_n128<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_sb_gemm_n128<KC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
@@ -2203,7 +2386,28 @@ int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const int64_t n_it = (R + 31) / 32;
     const int grid = n_it < cus ? (int)n_it : cus;
-    hipLaunchKernelGGL((k_sb_gemm_n128<KC>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu);
+    hipLaunchKernelGGL((k_sb_gemm_n128<KC, NT>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu);
+    return (int)hipGetLastError();
+}
+
+constexpr int SB_WGRAD_WGS = 256;  // one workgroup per CU (96 KB of LDS each)
+
+static bool sb_wgrad_shape_ok(int M, int N) {
+    return (M == 128 || M == 256 || M == 384) && (N == 128 || N == 256 || N == 384) && M + N <= 512 && M * N < 256 * 256;
+}
+
+template <int MT, int NT>
+int launch_sb_wgrad(int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *Cm, int accumulate, float *part, hipStream_t st) {
+    using C = SbWgCfg<MT, NT>;
+    static_assert(C::UNITS <= 512 && C::WGM * C::WGN == 8 && C::TM * C::WGM * 32 == C::M && C::TN * C::WGN * 32 == C::N && SB_DEPTH % 2 == 0, "tiling");
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_sb_wgrad<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_sb_wgrad<MT, NT>), dim3(SB_WGRAD_WGS), dim3(512), C::LDS_BYTES, st, A, lda, B, ldb, K, part);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((C::M * C::N + 63) / 64), dim3(256), 0, st, SB_WGRAD_WGS, C::M * C::N, (const float *)part, Cm, accumulate);
     return (int)hipGetLastError();
 }
 
@@ -2491,20 +2695,25 @@ int gru_cell_split_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_
     return (int)hipGetLastError();
 }
 
-int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *addend,
-                 int64_t lda, float *Y, int64_t ldy, void *stream) {
-    if (R < 0 || !X || !W || !Y || ldx < K || ldw < K || ldy < 128 || (addend && lda < 128)) return MO_ERR_BAD_ARG;
+int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu,
+            const float *addend, int64_t lda, float *Y, int64_t ldy, void *stream) {
+    if (R < 0 || !X || !W || !Y || ldx < K || ldw < K || ldy < N || (addend && lda < N)) return MO_ERR_BAD_ARG;
     if ((ldx & 3) || (ldw & 3) || (ldy & 3) || (lda & 3) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)addend & 15) ||
         ((uintptr_t)bias & 15))
         return MO_ERR_BAD_ARG;
     if (R == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    switch (K) {
-        case 128: return launch_sb_gemm<4>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
-        case 256: return launch_sb_gemm<8>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
-        case 384: return launch_sb_gemm<12>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
-    }
+    if (N == 128 && K == 128) return launch_sb_gemm<4, 1>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+    if (N == 128 && K == 256) return launch_sb_gemm<8, 1>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+    if (N == 128 && K == 384) return launch_sb_gemm<12, 1>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+    if (N == 256 && K == 128) return launch_sb_gemm<4, 2>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+    if (N == 384 && K == 128) return launch_sb_gemm<4, 3>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
     return MO_ERR_BAD_ARG;
+}
+
+int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *addend,
+                 int64_t lda, float *Y, int64_t ldy, void *stream) {
+    return sb_gemm(R, 128, K, X, ldx, W, ldw, bias, relu, addend, lda, Y, ldy, stream);
 }
 
 int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,
@@ -2590,6 +2799,23 @@ int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const
     else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, K, (int)M, (int)N, part);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((M * N + 63) / 64), dim3(256), 0, st, S, M * N, (const float *)part, C, (int)accumulate);
     return (int)hipGetLastError();
+}
+
+int64_t wgrad_split_workspace(int32_t M, int32_t N) {
+    if (!sb_wgrad_shape_ok(M, N)) return -1;
+    return (int64_t)SB_WGRAD_WGS * M * N * sizeof(float);
+}
+
+int wgrad_split_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
+                   void *workspace, void *stream) {
+    if (K < 1 || !sb_wgrad_shape_ok(M, N) || !A || !B || !C || !workspace) return MO_ERR_BAD_ARG;
+    if (lda < M || ldb < N || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return MO_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+#define SB_WG(mt, nt) if (M == 128 * mt && N == 128 * nt) return launch_sb_wgrad<mt, nt>(K, A, lda, B, ldb, C, accumulate, part, st);
+    SB_WG(1, 1) SB_WG(1, 2) SB_WG(2, 1) SB_WG(1, 3) SB_WG(3, 1)
+#undef SB_WG
+    return MO_ERR_BAD_ARG;
 }
 
 int fcra_neighbour_mean(int32_t R, int32_t P, int32_t E, int32_t T, const float *z_actor, int64_t za_episode_stride, int64_t za_step_stride,

@@ -232,8 +232,8 @@ class MAPPO:
         self.use_graphs = bool(rt.get("use_graphs", True))
         ug = rt.get("update_group", "auto")    # mini-batches per autograd graph in train(): "auto" | int (see _update_group)
         self.update_group = "auto" if str(ug) == "auto" else int(ug)
-        if rt.get("gru_cell") is not None:   # "split_bf16" (default) | "fp32": the rollout's GRU cell kernel (ops.set_cell_mode; process-wide)
-            ops.set_cell_mode(str(rt.get("gru_cell")))
+        if rt.get("matmul") is not None:   # "split_bf16" (default) | "fp32": how the fp32 matrix products are evaluated (ops.set_matmul_mode;
+            ops.set_matmul_mode(str(rt.get("matmul")))   # process-wide, like torch's float32 matmul precision switch)
         self.update_group_max_GB = float(rt.get("update_group_max_GB", 200.0))
         # depth 0: nothing reads buffer["{actor,critic}_historical_embedding"], so the rollout does not fill them (they stay zero;
         # the reference stores every tick's embedding regardless, DHGN/mappo_parallel.py:795-798).  true = record them anyway.

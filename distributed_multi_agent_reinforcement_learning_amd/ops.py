@@ -15,7 +15,7 @@ ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "sb_gemm", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "wgrad_split_tn", "wgrad_split_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -62,6 +62,7 @@ def load_library():
         L.gru_cell_fwd_multi.argtypes = [i32, vp, i32, i32, vp]
         L.gru_cell_split_fwd_multi.argtypes = [i32, vp, i32, i32, vp]
         L.sb_gemm_n128.argtypes = [i64, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp, i64, vp]
+        L.sb_gemm.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp, i64, vp]
         L.gru_seq_fwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_bwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_save_elems.argtypes = [i32, i32]
@@ -71,6 +72,9 @@ def load_library():
         L.wgrad_tn_workspace.argtypes = [i32, i32]
         L.wgrad_tn_workspace.restype = i64
         L.wgrad_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
+        L.wgrad_split_workspace.restype = i64
+        L.wgrad_split_workspace.argtypes = [i32, i32]
+        L.wgrad_split_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
         L.fcra_neighbour_mean.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, vp, vp, i64, vp]
         L.relu_bwd_colsum_workspace.argtypes = [i32]
         L.relu_bwd_colsum_workspace.restype = i64
@@ -550,6 +554,17 @@ def head_sample(feat, W, b, seed, counter, ticket, out, greedy=False):
 WGRAD_MIN_ROWS = 4096  # below this the BLAS library's single-workgroup-tile GEMMs are as fast
 
 
+# ---- how the fp32 matrix products of the hot path are evaluated ------------------------------------------------------------------
+# "split_bf16" (default): every fp32 operand is split EXACTLY into three bf16 numbers and a product is the six piece products with
+# i + j <= 4 on the bf16 matrix pipe with fp32 accumulation (csrc/mappo_ops.hip k_gru_cell_sb, k_sb_gemm_n128, k_sb_wgrad) -- fp32
+# inputs, outputs and stored tensors, the error against f64 of an fp32 GEMM (tests/test_ops_gpu.py), 2.67 x the fp32 matrix rate.
+# "fp32": v_mfma_f32_16x16x4_f32 kernels / the BLAS library's fp32 GEMMs.  One switch, `runtime.matmul` (MAPPO.__init__) or
+# set_matmul_mode(); the three parts can be switched separately through the environment for A/B measurements.
+MATMUL_MODE = os.environ.get("MAPPO_MATMUL", "split_bf16")
+WGRAD_MODE = os.environ.get("MAPPO_WGRAD", MATMUL_MODE)       # weight gradients (k_sb_wgrad | k_wgrad)
+SPLIT_WGRAD_SHAPES = {(128, 128), (128, 256), (256, 128), (128, 384), (384, 128)}
+
+
 def _wgrad_ok(a, b):
     return (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
             and a.shape[0] == b.shape[0] and a.shape[0] >= WGRAD_MIN_ROWS
@@ -572,6 +587,11 @@ def wgrad(a, b, out=None, accumulate=False):
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
         accumulate = False
     assert out.is_contiguous() and out.shape == (M, N)
+    if WGRAD_MODE == "split_bf16" and (M, N) in SPLIT_WGRAD_SHAPES:
+        ws = torch.empty(L.wgrad_split_workspace(M, N), dtype=torch.uint8, device=a.device)
+        _check(L.wgrad_split_tn(a.shape[0], M, N, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(bool(accumulate)), _ptr(ws), _stream()),
+               "wgrad_split_tn")
+        return out
     ws = torch.empty(L.wgrad_tn_workspace(M, N), dtype=torch.uint8, device=a.device)
     _check(L.wgrad_tn(a.shape[0], M, N, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), int(bool(accumulate)), _ptr(ws), _stream()),
            "wgrad_tn")
@@ -726,6 +746,16 @@ def _linear_fwd(x, W, b, out=None, relu=False, consume_addend=False):
     (no copy of b into a fresh result, no extra relu output); the returned tensor is b itself."""
     x2 = x.reshape(-1, W.shape[1])
     oshape = x.shape[:-1] + (W.shape[0],)
+    if out is None and x2.numel() and x2.stride(-1) == 1 and linear128_ok(x2, W, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
+        # the update's Linear layers on the split-bf16 kernel: bias / full addend / ReLU in its epilogue
+        if b is None or b.dim() == 1:
+            return linear128(x2, W, b, relu).view(oshape)
+        if b.is_contiguous():
+            b2 = b.view(-1, W.shape[0])
+            if consume_addend:
+                linear128(x2, W, None, relu, out=b2, addend=b2)
+                return b
+            return linear128(x2, W, None, relu, addend=b2).view(oshape)
     if consume_addend and b is not None and b.dim() > 1 and out is None and b.is_contiguous():
         y = b.view(-1, W.shape[0]).addmm_(x2, W.t())
         if relu:
@@ -777,11 +807,21 @@ class _Linear(torch.autograd.Function):
                 g = torch.ops.aten.threshold_backward(g, y, 0.0)
         g2 = g.reshape(-1, W.shape[0])
         x2 = x.reshape(-1, W.shape[1])
-        dx = torch.mm(g2, W).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dx = input_grad(g2, W).reshape(x.shape) if ctx.needs_input_grad[0] else None
         dW = wgrad(g2, x2) if ctx.needs_input_grad[1] else None
         if want_db and db is None:
             db = g2.sum(0) if ctx.bias_kind == 1 else g.reshape(ctx.b_shape)
         return dx, dW, db, None, None
+
+
+def input_grad(g2, W):
+    """g2 W for g2 (rows, N), W (N, K): the input gradient of a Linear layer -- on the split-bf16 kernel (as g2 (W^T)^T) where it
+    covers the shape, else the library"""
+    if g2.dim() == 2 and g2.stride(-1) == 1 and g2.is_cuda and PROJ_MODE == "split_bf16" and (W.shape[1], W.shape[0]) in UPDATE_SPLIT_SHAPES:
+        Wt = W.detach().t().contiguous()
+        if linear128_ok(g2, Wt, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
+            return linear128(g2, Wt)
+    return torch.mm(g2, W)
 
 
 def linear(x, W, b=None, out=None, relu=False, consume_addend=False):
@@ -844,6 +884,13 @@ def block2d(t):
     return t.as_strided((t.numel() // E, E), (_vec_stride(t), 1))
 
 
+def _hop_gemm(x, W, b, out):
+    """relu(x W^T + b) into a column block: the split-bf16 kernel where the update routes its Linear layers to it, else hipBLASLt"""
+    if linear128_ok(x, W, out, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
+        return linear128(x, W, b, True, out=out)
+    return gemm_nt(x, W, b, True, out=out)
+
+
 class _FcraHop(torch.autograd.Function):
     """One hop of DHGN.fcra (DHGN/mappo_parallel.py:204-233):  h' = relu([agg | h] Wf^T + bf),  agg = relu(nb Wagg^T + bagg).
     The reference concatenates; rounds 1-2 ran the FCRA layer as two accumulating GEMMs followed by a separate ReLU pass (and its
@@ -863,7 +910,7 @@ class _FcraHop(torch.autograd.Function):
             cat[:, E:].copy_(block2d(h))
         else:
             assert cat.shape == (rows, 2 * E) and cat.is_contiguous() and h.data_ptr() == cat.data_ptr() + E * cat.element_size()
-        gemm_nt(nb2, Wagg, bagg, True, out=cat[:, :E])
+        _hop_gemm(nb2, Wagg, bagg, cat[:, :E])
         nxt = None
         if out is not None:     # rollout: the caller's static storage (no autograd)
             ctx.mark_dirty(out)
@@ -873,7 +920,7 @@ class _FcraHop(torch.autograd.Function):
         else:
             nxt = torch.empty((rows, 2 * E), dtype=h.dtype, device=h.device)
             dst = nxt[:, E:]
-        gemm_nt(cat, Wf, bf, True, out=dst)
+        _hop_gemm(cat, Wf, bf, dst)
         box.append(nxt)
         ctx.save_for_backward(nb2, Wagg, Wf)
         # the two operand buffers are kept as plain references: the next hop writes the OTHER half of `nxt` in place, which bumps
@@ -893,7 +940,7 @@ class _FcraHop(torch.autograd.Function):
         except AssertionError:
             g2 = g.reshape(rows, E).contiguous()
         gin, dbf = relu_bwd_colsum(g2, y)
-        dcat = torch.mm(gin, Wf)                       # [d agg | d h]
+        dcat = input_grad(gin, Wf)                     # [d agg | d h]
         dWf = wgrad(gin, cat)
         ga, dbagg = relu_bwd_colsum(dcat[:, :E], cat[:, :E])
         dWagg = wgrad(ga, nb2)
@@ -995,7 +1042,7 @@ class _GRULayer(torch.autograd.Function):
         h0 = h0.contiguous()
         need = any(ctx.needs_input_grad)
         out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
-        gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())
+        gi = gru_input_projection(x.reshape(T * B, I), w_ih, b_ih)
         # the saved gates: (T, 4, B, H) planes for the per-step path; the persistent pair keeps them in its own lane order
         save = None
         if need:
@@ -1078,19 +1125,33 @@ class GruCellNet(C.Structure):
 # The rollout's GRU cells: "fp32" = v_mfma_f32_16x16x4_f32 (k_gru_cell), "split_bf16" = the same fp32 arithmetic from exact three-way
 # bf16 splits of the operands on v_mfma_f32_16x16x32_bf16 (k_gru_cell_sb, include/mappo_ops.h gru_cell_split_fwd_multi): same
 # results to fp32 rounding, 2.67 x the matrix rate.  `runtime.gru_cell` (MAPPO.__init__) or set_cell_mode().
-CELL_MODE = os.environ.get("MAPPO_GRU_CELL", "split_bf16")
+CELL_MODE = os.environ.get("MAPPO_GRU_CELL", MATMUL_MODE)     # the rollout: GRU cells and Linear layers
 
 
 def set_cell_mode(mode):
     global CELL_MODE
     if mode not in ("fp32", "split_bf16"):
-        raise ValueError(f"runtime.gru_cell={mode!r}: 'fp32' or 'split_bf16'")
+        raise ValueError(f"matmul mode {mode!r}: 'fp32' or 'split_bf16'")
     CELL_MODE = mode
 
 
-def linear128_ok(x, W, out=None, addend=None):
-    """shapes and strides sb_gemm_n128 covers: 128 outputs, 128 / 256 / 384 inputs, fp32, rows 16-byte aligned"""
-    if CELL_MODE != "split_bf16" or torch.is_grad_enabled() or not x.is_cuda or W.shape[0] != 128 or W.shape[1] not in (128, 256, 384):
+def set_matmul_mode(mode):
+    """all three parts at once (`runtime.matmul`)"""
+    global MATMUL_MODE, WGRAD_MODE, PROJ_MODE
+    set_cell_mode(mode)
+    MATMUL_MODE = WGRAD_MODE = PROJ_MODE = mode
+
+
+SPLIT_LINEAR_SHAPES = {(128, 128), (128, 256), (128, 384), (256, 128), (384, 128)}    # (outputs, inputs) sb_gemm covers
+# in the update (5e5-row operands) the 384-input kernel does not beat the library's GEMM (418 against 390 us): not routed there
+UPDATE_SPLIT_SHAPES = SPLIT_LINEAR_SHAPES - {(128, 384)}
+
+
+def linear128_ok(x, W, out=None, addend=None, mode=None, shapes=None):
+    """shapes and strides sb_gemm covers (fp32, rows 16-byte aligned, no autograd); mode: the switch that governs the caller
+    (default CELL_MODE, the rollout's kernels)"""
+    if ((CELL_MODE if mode is None else mode) != "split_bf16" or torch.is_grad_enabled() or not x.is_cuda
+            or tuple(W.shape) not in (SPLIT_LINEAR_SHAPES if shapes is None else shapes)):
         return False
     for t in (x, W) + ((out,) if out is not None else ()) + ((addend,) if addend is not None else ()):
         if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
@@ -1099,18 +1160,30 @@ def linear128_ok(x, W, out=None, addend=None):
 
 
 def linear128(x, W, bias=None, relu=False, out=None, addend=None):
-    """out = act(x W^T + bias + addend) for 2-D x (rows, K), W (128, K), out / addend (rows, 128), any row strides, in fp32
-    arithmetic on the bf16 matrix pipe (exact three-way operand splits, include/mappo_ops.h sb_gemm_n128).  The rollout's Linear
-    layers; no autograd.  addend may be out (accumulate in place)."""
+    """out = act(x W^T + bias + addend) for 2-D x (rows, K), W (N, K) with (N, K) in SPLIT_LINEAR_SHAPES, out / addend (rows, N), any
+    row strides, in fp32 arithmetic on the bf16 matrix pipe (exact three-way operand splits, include/mappo_ops.h sb_gemm).  The
+    rollout's Linear layers and the update's GRU input projections; no autograd.  addend may be out (accumulate in place)."""
     L = load_library()
     R, K = x.shape
+    N = W.shape[0]
     W = W.detach()
     if out is None:
-        out = torch.empty((R, 128), dtype=torch.float32, device=x.device)
+        out = torch.empty((R, N), dtype=torch.float32, device=x.device)
     b = bias.detach() if bias is not None else None
-    _check(L.sb_gemm_n128(R, K, _ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), int(bool(relu)), _ptr(addend),
-                          addend.stride(0) if addend is not None else 0, _ptr(out), out.stride(0), _stream()), "sb_gemm_n128")
+    _check(L.sb_gemm(R, N, K, _ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), int(bool(relu)), _ptr(addend),
+                     addend.stride(0) if addend is not None else 0, _ptr(out), out.stride(0), _stream()), "sb_gemm")
     return out
+
+
+# the update's Linear layers, their input gradients and the GRU input projections gi = x W_ih^T + b_ih: the BLAS library | sb_gemm
+PROJ_MODE = os.environ.get("MAPPO_PROJ", MATMUL_MODE)
+
+
+def gru_input_projection(x2, w_ih, b_ih):
+    """gi (rows, 384) = x2 w_ih^T + b_ih"""
+    if x2.stride(-1) == 1 and linear128_ok(x2, w_ih, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
+        return linear128(x2, w_ih, b_ih)
+    return torch.addmm(b_ih, x2, w_ih.t())
 
 
 def gru_step_multi(xs, hiddens, modules, hiddens_out=None):
@@ -1189,7 +1262,7 @@ class _GRULayerMulti(torch.autograd.Function):
             I, B = x.shape[-1], Bs[k]
             x, h0 = x.contiguous(), h0.contiguous()
             out = torch.empty((T, B, H), dtype=x.dtype, device=x.device)
-            gi = torch.addmm(b_ih, x.reshape(T * B, I), w_ih.t())
+            gi = gru_input_projection(x.reshape(T * B, I), w_ih, b_ih)
             save = torch.empty(L.gru_seq_save_elems(T, B), dtype=x.dtype, device=x.device) if need else None
             whh, bhh = w_hh.detach().contiguous(), b_hh.detach().contiguous()
             a = arr[k]

@@ -243,6 +243,10 @@ int gru_cell_split_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_
  * wider matrices); all pointers 16-byte aligned. */
 int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *C,
                  int64_t ldc, float *Y, int64_t ldy, void *stream);
+/* The same for N outputs: (N, K) in {(128, 128), (128, 256), (128, 384), (256, 128), (384, 128)} -- (384, 128) is a GRU input projection
+ * x W_ih^T + b_ih, (256, 128) the input gradient of an FCRA layer. */
+int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *C,
+            int64_t ldc, float *Y, int64_t ldy, void *stream);
 
 /*
  * PPO clipped-surrogate policy loss and clipped value loss of one mini-batch with their gradients
@@ -289,6 +293,11 @@ int rollout_record(int32_t N, int32_t n_items, const mo_record_item *items, cons
 int64_t wgrad_tn_workspace(int32_t M, int32_t N);
 int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
              void *workspace, void *stream);
+/* The same product in fp32 arithmetic on the bf16 matrix pipe (exact three-way operand splits, see gru_cell_split_fwd_multi): (M, N) in
+ * {128, 256, 384}^2 with M + N <= 512 and M N < 65536; workspace >= wgrad_split_workspace(M, N) bytes; deterministic. */
+int64_t wgrad_split_workspace(int32_t M, int32_t N);
+int wgrad_split_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
+                   void *workspace, void *stream);
 /*
  * Neighbour mean of DHGN.fcra (DHGN/mappo_parallel.py:204-233: `torch.matmul(F.normalize(adj, p=1, dim=-1), hist)`), R rows of P
  * agents and E features:  out[r][i][:] = act( sum_j abar[r][i][j] z[r][j][:] + bias ),  act = ReLU when relu != 0.

@@ -850,3 +850,31 @@ def test_split_bf16_linear128_matches_f64(K, R):
             assert float((y2.double() - x.double() @ W.double().t()).abs().max()) <= 2.0 * float((x @ W.t() - x.double() @ W.double().t()).abs().max()) + 1e-6
     finally:
         ops.set_cell_mode(old)
+
+
+@pytest.mark.parametrize("M,N", [(384, 128), (128, 384), (128, 128), (128, 256), (256, 128)])
+def test_split_bf16_wgrad_is_as_accurate_as_the_fp32_wgrad(M, N):
+    """ops.wgrad in both matmul modes against f64 (a^T b over 123 457 rows, strided operands): the split-bf16 kernel's error is the
+    fp32-MFMA kernel's (both a few 1e-7 of max |C|: summation order) -- and below the BLAS library's fp32 GEMM."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(M + N)
+    K = 123457
+    aw = torch.randn(K, M + 4, device="cuda") * torch.rand(K, 1, device="cuda")
+    a, b = aw[:, 4:], torch.randn(K, N, device="cuda")
+    ref = a.double().t() @ b.double()
+    old = ops.WGRAD_MODE
+    errs = {}
+    try:
+        for mode in ("fp32", "split_bf16"):
+            ops.WGRAD_MODE = mode
+            c = ops.wgrad(a, b)
+            c2 = ops.wgrad(a, b)
+            assert torch.equal(c, c2)                       # deterministic
+            acc = c.clone()
+            ops.wgrad(a, b, out=acc, accumulate=True)
+            assert torch.allclose(acc, 2 * c, rtol=1e-6, atol=1e-6)
+            errs[mode] = float((c.double() - ref).abs().max() / ref.abs().max())
+    finally:
+        ops.WGRAD_MODE = old
+    e_lib = float(((a.t() @ b).double() - ref).abs().max() / ref.abs().max())
+    assert errs["split_bf16"] < 3e-6 and errs["split_bf16"] <= 2.0 * errs["fp32"] + 2e-7, (errs, e_lib)
