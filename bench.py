@@ -440,7 +440,7 @@ def run_config(name, args, with_roofline):
                                        "bound": "instruction issue of the slowest wave (stragglers), not bytes",
                                        "us_per_launch": round(tk["replan"] * 1e6, 1), "us_max": round(tk["replan_max"] * 1e6, 1),
                                        "astar_expansions_mean": round(tk["astar_exp_mean"], 1), "astar_expansions_max": tk["astar_exp_max"]}
-        if rank == 0:
+        if rank == 0 and not args.no_kernel_probes:
             res["roofline_compute_kernels"] = measure_compute_kernels(tr, cfg)
     del tr
     gc.collect()
@@ -460,6 +460,7 @@ def main():
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--update-group", default=None, help="runtime.update_group: mini-batches per autograd graph of the update (default: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-probes", action="store_true", help="skip the isolated kernel timings (roofline_compute_kernels): profiling runs")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg3 measurement that rides along with cfg2")
     ap.add_argument("--tick-samples", type=int, default=150)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],

@@ -41,7 +41,8 @@ for cfg in ("cfg2", "cfg3"):
     for r in csv.DictReader(open(os.path.join(P, f"r03_bench_{cfg}_4096env_kernel_stats.csv"))):
         n, t = r["Name"], float(r["TotalDurationNs"]) / 1e6 / 4   # 2 set-up + 2 timed iterations in the profiled run
         key = ("gru_cell" if "k_gru_cell" in n else "gru_seq" if "k_gru_seq" in n or "k_gru_bias" in n else "skinny" if "skinny" in n
-               else "wgrad" if "k_wgrad" in n else "msg" if "k_msg" in n else "lib_gemm" if "Cijk" in n or "rocblas" in n
+               else "wgrad" if "k_wgrad" in n or "k_sb_wgrad" in n else "split_gemm" if "k_sb_gemm" in n else "msg" if "k_msg" in n
+               else "lib_gemm" if "Cijk" in n or "rocblas" in n
                else "env" if "k_tick" in n or "k_build" in n or "k_reset" in n
                else "aten" if "at::" in n or "elementwise" in n or "reduce_kernel" in n or "rocclr" in n else "small_own")
         cat[key] = cat.get(key, 0.0) + t

@@ -8,8 +8,10 @@ d = sys.argv[1]
 GROUPED = "--grouped" in sys.argv    # <dir> holds the passes of `tools/profile_gru.py --grouped`: 18 x 3280 + 2 x 3248 sequences per launch
 ROWS = 18 * 3280 + 2 * 3248 if GROUPED else 3280
 KERNELS = {"k_gru_seq_fwd2": 2.0 * 150 * ROWS * 128 * 384, "k_gru_seq_bwd2": 2.0 * 150 * ROWS * 384 * 128}
-if not GROUPED:
-    KERNELS.update({"k_gru_cell": 2.0 * 32768 * 128 * 768, "k_wgrad<3, 1>": 2.0 * 492000 * 384 * 128})
+if not GROUPED:   # substring -> algorithmic fp32 flops per launch ("k_gru_cell(" so that it does not match k_gru_cell_sb)
+    KERNELS.update({"k_gru_cell(": 2.0 * 32768 * 128 * 768, "k_gru_cell_sb": 2 * 2.0 * 32768 * 128 * 768, "k_wgrad<3, 1>": 2.0 * 492000 * 384 * 128,
+                    "k_sb_wgrad<3, 1>": 2.0 * 492000 * 384 * 128, "k_sb_gemm_n128<4, 1>": 2.0 * 196608 * 128 * 128,
+                    "k_sb_gemm_n128<12, 1>": 2.0 * 65536 * 384 * 128, "k_sb_gemm_n128<4, 3>": 2.0 * 492000 * 128 * 384})
 cnt = {}
 SUB = "grug" if GROUPED else "gru"    # the passes of tools/profile_all.sh: <dir>/gru_c, gru_t (single layer), grug_c, grug_t (grouped)
 for f in glob.glob(os.path.join(d, SUB + "_c", "**", "*counter_collection.csv"), recursive=True):
@@ -34,6 +36,8 @@ for k, fl in KERNELS.items():
         e["avg_duration_us"] = round(dur[k] * 1e6, 1)
         e["algorithmic_TFLOPs"] = round(fl / dur[k] / 1e12, 2)
         e["frac_of_157.3_TFLOPs"] = round(fl / dur[k] / 157.3e12, 4)
+        if "_sb" in k:   # the split-bf16 kernels run six bf16 MFMAs per product: their pipe peaks at 2500 / 6 TFLOP/s fp32-equivalent
+            e["frac_of_bf16_pipe_div_6"] = round(fl / dur[k] / (2500e12 / 6), 4)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         e["MfmaUtil_percent"] = round(100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 2)
     out["kernels"][k + (" (grouped: 20 layers, 65 536 sequences, 4 096 workgroups per launch)" if GROUPED else "")] = e

@@ -36,7 +36,19 @@ for rep in range(4):   # k_gru_seq_fwd + k_gru_seq_bwd + k_wgrad (the sequence m
     out.backward(torch.randn_like(out))
 xr, hr = torch.randn(1, Br, 128, device=dev), torch.randn(1, Br, 128, device=dev)
 with torch.no_grad():
-    for rep in range(20):  # k_gru_cell (one rollout step)
+    for rep in range(20):  # k_gru_cell (one rollout step, fp32 MFMA: the evaluator's path and runtime.matmul: fp32)
         ops.gru(xr, hr, gm)
+    # what the tick launches by default: actor's and critic's cell in one launch on exact bf16 operand splits (k_gru_cell_sb)
+    xs, hs, ho = [xr[0], xr[0].clone()], [hr, hr.clone()], [torch.empty_like(hr), torch.empty_like(hr)]
+    for rep in range(20):
+        ops.gru_step_multi(xs, hs, [gm, gm], hiddens_out=ho)
+    # the rollout's Linear layers (k_sb_gemm_n128) at the tick's shapes, and a mini-batch's GRU input projection (384 outputs)
+    m3 = torch.randn(6 * Br, 128, device=dev); e3 = torch.randn(2 * Br, 384, device=dev); o2 = torch.randn(2 * Br, 128, device=dev)
+    W1, W3, b1 = w(128, 128), w(128, 384), torch.zeros(128, device=dev)
+    xg, Wg, bg = torch.randn(Kr, 128, device=dev), w(384, 128), torch.zeros(384, device=dev)
+    for rep in range(10):
+        ops.linear128(m3, W1, b1, True)
+        ops.linear128(e3, W3, None, False, out=o2, addend=o2)
+        ops.linear128(xg, Wg, bg)
 torch.cuda.synchronize()
 print("done")
