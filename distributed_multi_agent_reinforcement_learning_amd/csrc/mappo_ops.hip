@@ -1191,6 +1191,8 @@ __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, GruCellNets n
 // a2 b3 + a3 b2 + a3 b3 < 2^-23 |a b|: one fp32 rounding of the product -- the accumulation is fp32 either way.  Six bf16 MFMAs per 32
 // contraction steps replace eight fp32 ones at half the cycles each: 2.67 x the matrix rate with fp32 inputs, fp32 outputs, and the
 // same error against f64 as the fp32 kernel (tests/test_ops_gpu.py).  Only operands are split, nothing is stored in bf16.
+// Domain: finite inputs up to bf16's largest finite value (3.39e38; fp32's is 3.40e38 -- beyond it the first piece rounds to infinity),
+// which activations, weights and gradients of this model are ~30 orders of magnitude away from.
 // Layout: the weights of BOTH projections as three pieces each are 590 KB -- more than a CU's registers --, so a 16-row tile is
 // shared by TWO workgroups, each owning 64 hidden units (their r, z and n rows of W_ih and W_hh: 144 registers per lane as MFMA
 // A-operands, split once in the prologue).  Wave (g, role): units 16 g .. 16 g + 15 of the half; role 0 accumulates r (input +
