@@ -152,16 +152,16 @@ class DHGN(nn.Module):
                                o_kvalid, q_div, pos=(Ws[:, :ind], self.semantic_layer.bias, h0) if fused_pos else None)   # (2, R, P, 3, E)
         agg0 = self.AGG_layers["AGG_vertex_0"]
         m3_2d = m3.view(-1, E)
-        if ops.linear128_ok(m3_2d, agg0.weight):     # the rollout's Linear layers on the split-bf16 kernel (ops.CELL_MODE)
-            emb = ops.linear128(m3_2d, agg0.weight, agg0.bias, relu=True).view(m3.shape)
+        if ops.split_linear_ok(m3_2d, agg0.weight):     # the rollout's Linear layers on the split-bf16 kernel (ops.CELL_MODE)
+            emb = ops.split_linear(m3_2d, agg0.weight, agg0.bias, relu=True).view(m3.shape)
         else:
             emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)
         if not fused_pos:
             torch.addmm(self.semantic_layer.bias, p.reshape(R * P, ind), Ws[:, :ind].t(), out=h0_2d[:R * P])
             h0_2d[R * P:].copy_(h0_2d[:R * P])
         emb_2d, Wse = emb.view(2 * R * P, 3 * E), Ws[:, ind:]
-        if ops.linear128_ok(emb_2d, Wse, h0_2d, h0_2d):
-            ops.linear128(emb_2d, Wse, None, False, out=h0_2d, addend=h0_2d)
+        if ops.split_linear_ok(emb_2d, Wse, h0_2d, h0_2d):
+            ops.split_linear(emb_2d, Wse, None, False, out=h0_2d, addend=h0_2d)
         elif d:   # h0 is the right half of the first hop's operand: accumulate into it in place (beta = 1, strided output)
             ops.gemm_nt(emb_2d, Wse, None, False, out=h0_2d, addend=h0_2d)
         else:
@@ -175,8 +175,8 @@ class DHGN(nn.Module):
             # the same history list, so the GEMM runs once for the two of them; the two neighbour means, the bias
             # and the ReLU are one launch that writes the left half of the hop's operand
             def lin(z, W=aggk.weight):
-                if z.is_contiguous() and ops.linear128_ok(z.view(-1, E), W):
-                    return ops.linear128(z.view(-1, E), W).view(z.shape)
+                if z.is_contiguous() and ops.split_linear_ok(z.view(-1, E), W):
+                    return ops.split_linear(z.view(-1, E), W).view(z.shape)
                 return ops.linear(z, W)
             za = lin(hist_a[k])
             zc = za if hist_c[k] is hist_a[k] or hist_c[k].data_ptr() == hist_a[k].data_ptr() else lin(hist_c[k])
@@ -187,8 +187,8 @@ class DHGN(nn.Module):
             else:
                 h = out if out is not None else torch.empty((2, R, P, E), dtype=p.dtype, device=p.device)
             cat_2d, h_2d = cats[k].view(2 * R * P, 2 * E), ops.block2d(h)
-            if ops.linear128_ok(cat_2d, fk.weight, h_2d):
-                ops.linear128(cat_2d, fk.weight, fk.bias, True, out=h_2d)
+            if ops.split_linear_ok(cat_2d, fk.weight, h_2d):
+                ops.split_linear(cat_2d, fk.weight, fk.bias, True, out=h_2d)
             else:
                 ops.gemm_nt(cat_2d, fk.weight, fk.bias, True, out=h_2d)
         return h

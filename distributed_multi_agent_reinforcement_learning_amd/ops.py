@@ -746,16 +746,16 @@ def _linear_fwd(x, W, b, out=None, relu=False, consume_addend=False):
     (no copy of b into a fresh result, no extra relu output); the returned tensor is b itself."""
     x2 = x.reshape(-1, W.shape[1])
     oshape = x.shape[:-1] + (W.shape[0],)
-    if out is None and x2.numel() and x2.stride(-1) == 1 and linear128_ok(x2, W, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
+    if out is None and x2.numel() and x2.stride(-1) == 1 and split_linear_ok(x2, W, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
         # the update's Linear layers on the split-bf16 kernel: bias / full addend / ReLU in its epilogue
         if b is None or b.dim() == 1:
-            return linear128(x2, W, b, relu).view(oshape)
+            return split_linear(x2, W, b, relu).view(oshape)
         if b.is_contiguous():
             b2 = b.view(-1, W.shape[0])
             if consume_addend:
-                linear128(x2, W, None, relu, out=b2, addend=b2)
+                split_linear(x2, W, None, relu, out=b2, addend=b2)
                 return b
-            return linear128(x2, W, None, relu, addend=b2).view(oshape)
+            return split_linear(x2, W, None, relu, addend=b2).view(oshape)
     if consume_addend and b is not None and b.dim() > 1 and out is None and b.is_contiguous():
         y = b.view(-1, W.shape[0]).addmm_(x2, W.t())
         if relu:
@@ -819,8 +819,8 @@ def input_grad(g2, W):
     covers the shape, else the library"""
     if g2.dim() == 2 and g2.stride(-1) == 1 and g2.is_cuda and PROJ_MODE == "split_bf16" and (W.shape[1], W.shape[0]) in UPDATE_SPLIT_SHAPES:
         Wt = W.detach().t().contiguous()
-        if linear128_ok(g2, Wt, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
-            return linear128(g2, Wt)
+        if split_linear_ok(g2, Wt, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
+            return split_linear(g2, Wt)
     return torch.mm(g2, W)
 
 
@@ -886,8 +886,8 @@ def block2d(t):
 
 def _hop_gemm(x, W, b, out):
     """relu(x W^T + b) into a column block: the split-bf16 kernel where the update routes its Linear layers to it, else hipBLASLt"""
-    if linear128_ok(x, W, out, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
-        return linear128(x, W, b, True, out=out)
+    if split_linear_ok(x, W, out, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
+        return split_linear(x, W, b, True, out=out)
     return gemm_nt(x, W, b, True, out=out)
 
 
@@ -1147,7 +1147,7 @@ SPLIT_LINEAR_SHAPES = {(128, 128), (128, 256), (128, 384), (256, 128), (384, 128
 UPDATE_SPLIT_SHAPES = SPLIT_LINEAR_SHAPES - {(128, 384)}
 
 
-def linear128_ok(x, W, out=None, addend=None, mode=None, shapes=None):
+def split_linear_ok(x, W, out=None, addend=None, mode=None, shapes=None):
     """shapes and strides sb_gemm covers (fp32, rows 16-byte aligned, no autograd); mode: the switch that governs the caller
     (default CELL_MODE, the rollout's kernels)"""
     if ((CELL_MODE if mode is None else mode) != "split_bf16" or torch.is_grad_enabled() or not x.is_cuda
@@ -1159,7 +1159,7 @@ def linear128_ok(x, W, out=None, addend=None, mode=None, shapes=None):
     return x.shape[1] == W.shape[1]
 
 
-def linear128(x, W, bias=None, relu=False, out=None, addend=None):
+def split_linear(x, W, bias=None, relu=False, out=None, addend=None):
     """out = act(x W^T + bias + addend) for 2-D x (rows, K), W (N, K) with (N, K) in SPLIT_LINEAR_SHAPES, out / addend (rows, N), any
     row strides, in fp32 arithmetic on the bf16 matrix pipe (exact three-way operand splits, include/mappo_ops.h sb_gemm).  The
     rollout's Linear layers and the update's GRU input projections; no autograd.  addend may be out (accumulate in place)."""
@@ -1181,8 +1181,8 @@ PROJ_MODE = os.environ.get("MAPPO_PROJ", MATMUL_MODE)
 
 def gru_input_projection(x2, w_ih, b_ih):
     """gi (rows, 384) = x2 w_ih^T + b_ih"""
-    if x2.stride(-1) == 1 and linear128_ok(x2, w_ih, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
-        return linear128(x2, w_ih, b_ih)
+    if x2.stride(-1) == 1 and split_linear_ok(x2, w_ih, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
+        return split_linear(x2, w_ih, b_ih)
     return torch.addmm(b_ih, x2, w_ih.t())
 
 

@@ -821,8 +821,8 @@ def test_gru_step_multi_equals_separate_cells(B):
 
 
 @pytest.mark.parametrize("K,R", [(128, 196608), (256, 65536), (384, 65536), (128, 37), (384, 1)])
-def test_split_bf16_linear128_matches_f64(K, R):
-    """ops.linear128 (sb_gemm_n128): act(x W^T + b + addend) for 128 outputs on exact three-way bf16 splits, strided operands (column
+def test_split_bf16_linear_matches_f64(K, R):
+    """ops.split_linear (sb_gemm): act(x W^T + b + addend) for 128 outputs on exact three-way bf16 splits, strided operands (column
     blocks of wider matrices), in-place accumulation; the error against f64 is that of a plain fp32 GEMM (torch.mm)."""
     from distributed_multi_agent_reinforcement_learning_amd import ops
     old = ops.CELL_MODE
@@ -838,15 +838,15 @@ def test_split_bf16_linear128_matches_f64(K, R):
         out = wide[:, 128:]
         add0 = out.clone()
         with torch.no_grad():
-            assert ops.linear128_ok(x, W, out, out)
-            y = ops.linear128(x, W, b, True, out=out, addend=out)
+            assert ops.split_linear_ok(x, W, out, out)
+            y = ops.split_linear(x, W, b, True, out=out, addend=out)
             ref = torch.relu(x.double() @ W.double().t() + b.double() + add0.double())
             lib = torch.relu(torch.addmm(add0 + b, x, W.t()))
             assert y.data_ptr() == out.data_ptr()
             e_split, e_lib = float((y.double() - ref).abs().max()), float((lib.double() - ref).abs().max())
             assert e_split <= 2.0 * e_lib + 1e-6 and e_split < 2e-5 * max(1.0, float(ref.abs().max())), (e_split, e_lib)
             assert torch.equal(wide[:, :128], wide[:, :128])  # the left block is not touched (checked below against a copy)
-            y2 = ops.linear128(x, W)                          # no bias, no addend, fresh output
+            y2 = ops.split_linear(x, W)                          # no bias, no addend, fresh output
             assert float((y2.double() - x.double() @ W.double().t()).abs().max()) <= 2.0 * float((x @ W.t() - x.double() @ W.double().t()).abs().max()) + 1e-6
     finally:
         ops.set_cell_mode(old)

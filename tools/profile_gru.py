@@ -47,8 +47,8 @@ with torch.no_grad():
     W1, W3, b1 = w(128, 128), w(128, 384), torch.zeros(128, device=dev)
     xg, Wg, bg = torch.randn(Kr, 128, device=dev), w(384, 128), torch.zeros(384, device=dev)
     for rep in range(10):
-        ops.linear128(m3, W1, b1, True)
-        ops.linear128(e3, W3, None, False, out=o2, addend=o2)
-        ops.linear128(xg, Wg, bg)
+        ops.split_linear(m3, W1, b1, True)
+        ops.split_linear(e3, W3, None, False, out=o2, addend=o2)
+        ops.split_linear(xg, Wg, bg)
 torch.cuda.synchronize()
 print("done")

@@ -1,5 +1,5 @@
-"""The rollout's Linear layers: the split-bf16 kernel (ops.linear128) beside the library GEMM at the tick's shapes.
-python tools/linear128_probe.py"""
+"""The rollout's Linear layers: the split-bf16 kernel (ops.split_linear) beside the library GEMM at the tick's shapes.
+python tools/split_linear_probe.py"""
 import os
 import sys
 
@@ -29,7 +29,7 @@ with torch.no_grad():
                                         ("FCRA AGG", 32768, 128, False, False, False), ("FCRA layer", 65536, 256, True, True, False)):
         x = torch.randn(R, K, device=dev); W = torch.randn(128, K, device=dev) * 0.1; b = torch.randn(128, device=dev) if bias else None
         out = torch.randn(R, 128, device=dev)
-        t_s = timed(lambda: ops.linear128(x, W, b, relu, out=out, addend=out if acc else None))
+        t_s = timed(lambda: ops.split_linear(x, W, b, relu, out=out, addend=out if acc else None))
         t_l = timed(lambda: ops.gemm_nt(x, W, b, relu, out=out, addend=out if acc else None))
         gb = (R * K + R * 128 * (2 if acc else 1)) * 4
         print(f"{name:36s} {R:7d} x {K:3d}: split {t_s:6.1f} us ({2.0 * R * K * 128 / t_s / 1e6:6.1f} TFLOP/s, {gb / t_s / 1e3:5.0f} GB/s)   library {t_l:6.1f} us")
@@ -37,15 +37,15 @@ with torch.no_grad():
 with torch.no_grad():     # the update's GRU input projection (one mini-batch): 384 outputs
     R = 492000
     x = torch.randn(R, 128, device=dev); W = torch.randn(384, 128, device=dev) * 0.1; b = torch.randn(384, device=dev)
-    t_s = timed(lambda: ops.linear128(x, W, b), n=20)
+    t_s = timed(lambda: ops.split_linear(x, W, b), n=20)
     t_l = timed(lambda: torch.addmm(b, x, W.t()), n=20)
     ref = x[:4096].double() @ W.double().t() + b.double()
-    e_s = float((ops.linear128(x[:4096], W, b).double() - ref).abs().max()); e_l = float((torch.addmm(b, x[:4096], W.t()).double() - ref).abs().max())
+    e_s = float((ops.split_linear(x[:4096], W, b).double() - ref).abs().max()); e_l = float((torch.addmm(b, x[:4096], W.t()).double() - ref).abs().max())
     print(f"GRU input projection {R} x 128 -> 384: split {t_s:6.1f} us ({(R * 512 * 4) / t_s / 1e3:5.0f} GB/s, max err {e_s:.1e})   library {t_l:6.1f} us (max err {e_l:.1e})")
 with torch.no_grad():     # the update's input gradients of a GRU projection / the semantic layer at one mini-batch: 384 inputs
     for R, K in ((492000, 384), (492000, 128), (1476000, 128)):
         x = torch.randn(R, K, device=dev); W = torch.randn(128, K, device=dev) * 0.1
         out = torch.empty(R, 128, device=dev)
-        t_s = timed(lambda: ops.linear128(x, W, None, False, out=out), n=10)
+        t_s = timed(lambda: ops.split_linear(x, W, None, False, out=out), n=10)
         t_l = timed(lambda: torch.mm(x, W.t(), out=out), n=10)
         print(f"{R} x {K} -> 128: split {t_s:6.1f} us ({(R * (K + 128) * 4) / t_s / 1e3:5.0f} GB/s)   library {t_l:6.1f} us")
