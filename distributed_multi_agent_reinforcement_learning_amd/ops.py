@@ -1143,8 +1143,9 @@ def set_matmul_mode(mode):
 
 
 SPLIT_LINEAR_SHAPES = {(128, 128), (128, 256), (128, 384), (256, 128), (384, 128)}    # (outputs, inputs) sb_gemm covers
-# in the update (5e5-row operands) the 384-input kernel does not beat the library's GEMM (418 against 390 us): not routed there
-UPDATE_SPLIT_SHAPES = SPLIT_LINEAR_SHAPES - {(128, 384)}
+# the update routes all of them as well (5e5-row operands: the 384-input kernel is matrix + vector bound there, 398 us against the
+# library's 420-484 us, worth 1 ms per iteration; the 128-input kernels run at HBM speed, 2 x the library)
+UPDATE_SPLIT_SHAPES = SPLIT_LINEAR_SHAPES
 
 
 def split_linear_ok(x, W, out=None, addend=None, mode=None, shapes=None):
