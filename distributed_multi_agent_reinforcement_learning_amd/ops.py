@@ -1107,7 +1107,7 @@ class _GRULayer(torch.autograd.Function):
         dw_ih = wgrad(dgi, x2)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dgi, w_ih)
+            dx = input_grad(dgi, w_ih)
             if ctx.ungather:   # back to the caller's (episode, step, agent) rows
                 P = ctx.ungather
                 dx = dx.reshape(T, B // P, P, I).permute(1, 0, 2, 3)
@@ -1316,7 +1316,7 @@ class _GRULayerMulti(torch.autograd.Function):
             dw_hh = _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H)
             I = x.shape[-1]
             dw_ih = wgrad(dgi, x.reshape(T * B, I))
-            dx = torch.mm(dgi, w_ih).reshape(ctx.x_shapes[k]) if ctx.needs_input_grad[3 + 6 * k] else None
+            dx = input_grad(dgi, w_ih).reshape(ctx.x_shapes[k]) if ctx.needs_input_grad[3 + 6 * k] else None
             grads += [dx, dh0, dw_ih, dw_hh, db_ih, db_hh]
         return tuple(grads)
 
