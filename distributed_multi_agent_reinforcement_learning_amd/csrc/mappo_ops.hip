@@ -1439,11 +1439,30 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
         f32x4 acc[NT][2];
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t][0] = acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the operands of chunk c + 1 are read while chunk c is multiplied (pinned with scheduling barriers: left alone, the compiler
+        // issues a chunk's reads after the previous chunk's MFMAs and the matrix pipe drains behind every LDS round trip)
+        // (the HBM-bound 128 x 128 variant is better off without: 106 against 114 us at 492 000 rows)
+        constexpr bool AHEAD = KC * NT > 4;
+        uint4 nb0[3], nb1[3];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int p = 0; p < 3; p++) { nb0[p] = tb[(p * KC * 2) * 64]; nb1[p] = tb[(p * KC * 2 + 1) * 64]; }
+        }
 #pragma unroll
         for (int c = 0; c < KC; c++) {
             uint4 b0[3], b1[3];
+            if constexpr (AHEAD) {
 #pragma unroll
-            for (int p = 0; p < 3; p++) { b0[p] = tb[(p * KC * 2 + 2 * c) * 64]; b1[p] = tb[(p * KC * 2 + 2 * c + 1) * 64]; }
+                for (int p = 0; p < 3; p++) { b0[p] = nb0[p]; b1[p] = nb1[p]; }
+                if (c + 1 < KC) {
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { nb0[p] = tb[(p * KC * 2 + 2 * c + 2) * 64]; nb1[p] = tb[(p * KC * 2 + 2 * c + 3) * 64]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 3; p++) { b0[p] = tb[(p * KC * 2 + 2 * c) * 64]; b1[p] = tb[(p * KC * 2 + 2 * c + 1) * 64]; }
+            }
 #define SBG_MMA(pi, pj)                                                                                                                             \
             _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                                                          \
                 acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b0[pj]), acc[t][0], 0, 0, 0); \
@@ -1451,6 +1470,7 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
             }
             SBG_MMA(2, 0) SBG_MMA(0, 2) SBG_MMA(1, 1) SBG_MMA(1, 0) SBG_MMA(0, 1) SBG_MMA(0, 0)
 #undef SBG_MMA
+            if constexpr (AHEAD) __builtin_amdgcn_sched_barrier(0);
         }
         if (it + gridDim.x < n_it) stage(sbg_tile + (cur ^ 1) * IMG);          // the rows fetched one iteration ago -> the other image
         if (it + 2 * (int64_t)gridDim.x < n_it) fetch(it + 2 * (int64_t)gridDim.x);
