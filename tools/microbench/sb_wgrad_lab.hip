@@ -1,8 +1,10 @@
-// sb_wgrad_lab.hip -- EXPERIMENT (not part of the product): the weight-gradient GEMM in fp32 arithmetic on the bf16 matrix pipe.
-// Result (profiles/r03_split_bf16_lab.txt): as accurate as the fp32-MFMA kernel (7.8e-7 against 5.9e-7 of max |C| for 492 000
-// rows; the BLAS library's fp32 GEMM: 6.7e-6), 414 us against 482 us alone -- and no faster inside the training iteration
-// (319.3 against 317.9 ms): with HBM, VALU, LDS and the matrix pipe all busy the shader clock falls to 1.6 GHz (2.2 GHz for
-// the matrix phase alone, 2.28 GHz on half the CUs), i.e. the chip is power-limited and the launch is no shorter than k_wgrad's.
+// sb_wgrad_lab.hip -- phase / clock lab of the weight-gradient GEMM in fp32 arithmetic on the bf16 matrix pipe (the product kernel is
+// k_sb_wgrad in csrc/mappo_ops.hip, same structure; this copy carries the probes).  Results (profiles/r03_split_bf16_lab.txt): as
+// accurate as the fp32-MFMA kernel (7.8e-7 against 5.9e-7 of max |C| for 492 000 rows; the BLAS library's fp32 GEMM: 6.7e-6), 414 us
+// against 482 us alone.  The first A/B inside the training iteration showed no gain (319.3 against 317.9 ms) because this file's
+// partial reduction (one thread per output walking 256 partials) cost the 40 us the kernel had won; with the product's four-wave
+// reduction the gain is 5.5 ms per iteration.  The clock figures stand: with HBM, VALU, LDS and the matrix pipe all busy the shader
+// clock falls to 1.6 GHz (2.2 GHz for the matrix phase alone, 2.28 GHz on half the CUs): the chip is power-limited.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSB_PROBE=n] [-DSB_WGS=n] [-DSB_CLOCK] tools/microbench/sb_wgrad_lab.hip -o tools/microbench/sb_wgrad_lab_n
 //   SB_PROBE: 1 no split arithmetic, 2 no LDS image, 3 no matrix phase, 4 no loads and no staging, 5 matrix pipe only
 //
