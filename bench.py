@@ -505,7 +505,9 @@ def main():
             "metric": "env-steps/sec (whole node), pursuit-evasion 8-agent 4096-env", "value": main_res["value"],
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64 environment / f32 policy", "data": "synthetic (seeded random maps, random-init weights)",
+            "dtype": ("f64 environment / f32 policy (f32 matrix products evaluated from exact 3-way bf16 operand splits, f32 accumulation and storage)"
+                      if main_res["matmul"] == "split_bf16" else "f64 environment / f32 policy"),
+            "data": "synthetic (seeded random maps, random-init weights)",
             "matmul": ("fp32 products from exact three-way bf16 splits of the fp32 operands (6 bf16 MFMAs per product, fp32 accumulation, fp32 storage; error "
                        "against f64 = an fp32 GEMM's, tests/test_ops_gpu.py); configs.cfg2_fp32_mfma is the same run on fp32 MFMA / BLAS"
                        if main_res["matmul"] == "split_bf16" else "fp32 MFMA kernels / BLAS library fp32 GEMMs"),
