@@ -2170,9 +2170,13 @@ struct NbrArgs {
     int64_t adj_rs;                     // elements between adjacency rows
     int64_t out_ld;                     // elements between the output vectors of consecutive agents (E: dense)
 };
+// several hops in one launch (blockIdx.y): the FCRA hops of a rollout tick read stored history slots, not each other
+struct NbrJobs { mo_nbr_job j[MO_NBR_MAX_JOBS]; };
 template <int PT>
-__global__ void k_nbr_mean(NbrArgs a, const float *__restrict__ za, const float *__restrict__ zc, const float *__restrict__ adj,
-                           const float *__restrict__ bias, float *__restrict__ out_a, float *__restrict__ out_c) {
+__global__ void k_nbr_mean(NbrArgs a, NbrJobs jobs, const float *__restrict__ adj) {
+    const mo_nbr_job &job = jobs.j[blockIdx.y];
+    const float *__restrict__ za = job.z_actor, *__restrict__ zc = job.z_critic, *__restrict__ bias = job.bias;
+    float *__restrict__ out_a = job.out_actor, *__restrict__ out_c = job.out_critic;
     const int P = a.P, E = a.E, f = threadIdx.x, lane = threadIdx.x & 63;
     const float bf = bias ? bias[f] : 0.f;
     const float inv_p = 1.f / fmaxf((float)P, 1e-12f);
@@ -2843,13 +2847,28 @@ int wgrad_split_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda,
 int fcra_neighbour_mean(int32_t R, int32_t P, int32_t E, int32_t T, const float *z_actor, int64_t za_episode_stride, int64_t za_step_stride,
                         const float *z_critic, int64_t zc_episode_stride, int64_t zc_step_stride, const float *adj, int64_t adj_row_stride,
                         const float *bias, int32_t relu, float *out_actor, float *out_critic, int64_t out_stride, void *stream) {
+    const mo_nbr_job job{z_actor, z_critic, bias, out_actor, out_critic};
+    return fcra_neighbour_mean_multi(1, &job, R, P, E, T, za_episode_stride, za_step_stride, zc_episode_stride, zc_step_stride, adj, adj_row_stride, relu,
+                                     out_stride, stream);
+}
+
+int fcra_neighbour_mean_multi(int32_t n_jobs, const mo_nbr_job *jobs, int32_t R, int32_t P, int32_t E, int32_t T, int64_t za_episode_stride,
+                              int64_t za_step_stride, int64_t zc_episode_stride, int64_t zc_step_stride, const float *adj, int64_t adj_row_stride,
+                              int32_t relu, int64_t out_stride, void *stream) {
+    if (n_jobs < 1 || n_jobs > MO_NBR_MAX_JOBS || !jobs) return MO_ERR_BAD_ARG;
     if (R < 0 || P < 1 || P > MAX_P || E < 64 || E > 1024 || (E & 63) || T < 1 || (R % T) || out_stride < E) return MO_ERR_BAD_ARG;
-    if ((out_actor && (!z_actor || !adj)) || (out_critic && !z_critic) || (!out_actor && !out_critic)) return MO_ERR_BAD_ARG;
+    NbrJobs a_jobs;
+    memset(&a_jobs, 0, sizeof a_jobs);
+    for (int k = 0; k < n_jobs; k++) {
+        const mo_nbr_job &m = jobs[k];
+        if ((m.out_actor && (!m.z_actor || !adj)) || (m.out_critic && !m.z_critic) || (!m.out_actor && !m.out_critic)) return MO_ERR_BAD_ARG;
+        a_jobs.j[k] = m;
+    }
     if (R == 0) return 0;
     NbrArgs a{R, P, E, T, relu, za_episode_stride, za_step_stride, zc_episode_stride, zc_step_stride, adj_row_stride, out_stride};
-    const int grid = R < 16384 ? R : 16384;
-    if (P <= 8) hipLaunchKernelGGL(k_nbr_mean<8>, dim3(grid), dim3(E), 0, (hipStream_t)stream, a, z_actor, z_critic, adj, bias, out_actor, out_critic);
-    else hipLaunchKernelGGL(k_nbr_mean<16>, dim3(grid), dim3(E), 0, (hipStream_t)stream, a, z_actor, z_critic, adj, bias, out_actor, out_critic);
+    const int per = 16384 / n_jobs, grid = R < per ? R : per;
+    if (P <= 8) hipLaunchKernelGGL(k_nbr_mean<8>, dim3(grid, n_jobs), dim3(E), 0, (hipStream_t)stream, a, a_jobs, adj);
+    else hipLaunchKernelGGL(k_nbr_mean<16>, dim3(grid, n_jobs), dim3(E), 0, (hipStream_t)stream, a, a_jobs, adj);
     return (int)hipGetLastError();
 }
 

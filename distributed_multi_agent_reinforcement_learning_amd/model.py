@@ -169,18 +169,28 @@ class DHGN(nn.Module):
         if d == 0:
             return h0
         h = h0
+        # relu((abar @ hist) W^T + b) evaluated as relu(abar @ (hist W^T) + b): in the reference's rollout both networks read the same
+        # history list, so the GEMM runs once for the two of them.  Every hop's aggregate depends on stored history only,
+        # so the d neighbour means (both networks each, bias and ReLU included) are ONE launch that writes the left halves of all
+        # hops' operands before the chain of FCRA layers runs
+        zas, zcs = [], []
         for k in range(d):
-            aggk, fk = self.AGG_layers[f"AGG_fcra_{k}"], self.FCRA_layers[k]
-            # relu((abar @ hist) W^T + b) evaluated as relu(abar @ (hist W^T) + b): in the reference's rollout both networks read
-            # the same history list, so the GEMM runs once for the two of them; the two neighbour means, the bias
-            # and the ReLU are one launch that writes the left half of the hop's operand
+            aggk = self.AGG_layers[f"AGG_fcra_{k}"]
+
             def lin(z, W=aggk.weight):
                 if z.is_contiguous() and ops.split_linear_ok(z.view(-1, E), W):
                     return ops.split_linear(z.view(-1, E), W).view(z.shape)
                 return ops.linear(z, W)
             za = lin(hist_a[k])
-            zc = za if hist_c[k] is hist_a[k] or hist_c[k].data_ptr() == hist_a[k].data_ptr() else lin(hist_c[k])
-            ops.fcra_mean(z_actor=za, z_critic=zc, adj=adj_p, bias=aggk.bias, relu=True, out=cats[k][..., :E])
+            zcs.append(za if hist_c[k] is hist_a[k] or hist_c[k].data_ptr() == hist_a[k].data_ptr() else lin(hist_c[k]))
+            zas.append(za)
+        if d <= 4 and all(z.is_contiguous() for z in zas + zcs) and adj_p.dtype == torch.float32:
+            ops.fcra_mean_pair_multi(zas, zcs, adj_p, [self.AGG_layers[f"AGG_fcra_{k}"].bias for k in range(d)], [cats[k][..., :E] for k in range(d)])
+        else:
+            for k in range(d):
+                ops.fcra_mean(z_actor=zas[k], z_critic=zcs[k], adj=adj_p, bias=self.AGG_layers[f"AGG_fcra_{k}"].bias, relu=True, out=cats[k][..., :E])
+        for k in range(d):
+            fk = self.FCRA_layers[k]
             last = k == d - 1
             if not last:
                 h = cats[k + 1][..., E:]

@@ -76,6 +76,7 @@ def load_library():
         L.wgrad_split_workspace.argtypes = [i32, i32]
         L.wgrad_split_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
         L.fcra_neighbour_mean.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, vp, vp, i64, vp]
+        L.fcra_neighbour_mean_multi.argtypes = [i32, vp, i32, i32, i32, i32, i64, i64, i64, i64, vp, i64, i32, i64, vp]
         L.relu_bwd_colsum_workspace.argtypes = [i32]
         L.relu_bwd_colsum_workspace.restype = i64
         L.relu_bwd_colsum.argtypes = [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp]
@@ -639,6 +640,36 @@ def fcra_mean(z_actor=None, z_critic=None, adj=None, bias=None, relu=False, out=
                                  _ptr(bias.detach() if bias is not None else None), int(bool(relu)), _ptr(o_a), _ptr(o_c), out_ld, _stream()),
            "fcra_neighbour_mean")
     return out
+
+
+class NbrJob(C.Structure):
+    """include/mappo_ops.h mo_nbr_job"""
+    _fields_ = [(n, C.c_void_p) for n in ("z_actor", "z_critic", "bias", "out_actor", "out_critic")]
+
+
+def fcra_mean_pair_multi(zas, zcs, adj, biases, outs):
+    """fcra_mean(z_actor=za, z_critic=zc, adj=adj, bias=b, relu=True, out=o) for several hops (za, zc, b, o) of one shape in ONE launch
+    (fcra_neighbour_mean_multi): the hops of a rollout tick read stored history slots, none reads another hop's result.
+    za, zc: dense (R, P, E); o: (2, R, P, E) storage (possibly the left half of an [agg | h] operand)."""
+    L = load_library()
+    n = len(zas)
+    assert 1 <= n <= 4 and len(zcs) == n and len(biases) == n and len(outs) == n
+    P, E = zas[0].shape[-2], zas[0].shape[-1]
+    R = zas[0].numel() // (P * E)
+    out_ld = _vec_stride(outs[0])
+    arr = (NbrJob * n)()
+    keep = []
+    for k in range(n):
+        za, zc, o = zas[k], zcs[k], outs[k]
+        assert za.is_contiguous() and zc.is_contiguous() and za.shape == zas[0].shape and zc.shape == zas[0].shape and _vec_stride(o) == out_ld
+        b = biases[k].detach()
+        keep.append(b)
+        a = arr[k]
+        a.z_actor, a.z_critic, a.bias, a.out_actor, a.out_critic = za.data_ptr(), zc.data_ptr(), b.data_ptr(), o[0].data_ptr(), o[1].data_ptr()
+    adj3 = adj.reshape(R, P, P)
+    assert adj3.dtype == torch.float32 and _rows_ok(adj3)
+    _check(L.fcra_neighbour_mean_multi(n, C.cast(arr, C.c_void_p), R, P, E, 1, P * E, 0, P * E, 0, _ptr(adj3), adj3.stride(0), 1, out_ld, _stream()),
+           "fcra_neighbour_mean_multi")
 
 
 RELU_BWD_MIN_ROWS = 4096

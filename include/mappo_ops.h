@@ -311,6 +311,13 @@ int wgrad_split_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda,
 int fcra_neighbour_mean(int32_t R, int32_t P, int32_t E, int32_t T, const float *z_actor, int64_t za_episode_stride, int64_t za_step_stride,
                         const float *z_critic, int64_t zc_episode_stride, int64_t zc_step_stride, const float *adj, int64_t adj_row_stride,
                         const float *bias, int32_t relu, float *out_actor, float *out_critic, int64_t out_stride, void *stream);
+/* Several such aggregations of one shape in ONE launch (the FCRA hops of a rollout tick: every hop reads a stored history slot, none
+ * reads another hop's result): same R, P, E, T, strides, adjacency, relu and out_stride; own inputs, bias and outputs per job. */
+#define MO_NBR_MAX_JOBS 4
+typedef struct mo_nbr_job { const float *z_actor, *z_critic, *bias; float *out_actor, *out_critic; } mo_nbr_job;
+int fcra_neighbour_mean_multi(int32_t n_jobs, const mo_nbr_job *jobs, int32_t R, int32_t P, int32_t E, int32_t T, int64_t za_episode_stride,
+                              int64_t za_step_stride, int64_t zc_episode_stride, int64_t zc_step_stride, const float *adj, int64_t adj_row_stride,
+                              int32_t relu, int64_t out_stride, void *stream);
 
 /*
  * ReLU backward and the bias gradient of the Linear in front of it in one pass (autograd: aten::threshold_backward, then
