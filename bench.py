@@ -361,6 +361,11 @@ def run_config(name, args, with_roofline):
         if total % world:
             raise SystemExit(f"--scaling strong: {total} environments do not divide over {world} ranks")
         cfg.runtime.num_envs = total // world
+    if torch.cuda.is_available():
+        import gc
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())   # this rank's GPU (what Trainer selects), not device 0
+        gc.collect()
+        torch.cuda.empty_cache()   # a previous configuration's cached blocks (the grouped epoch holds 125-171 GB) go back to the driver
     tr = Trainer(cfg)  # weak scaling: every rank owns runtime.num_envs environments
     N, T, P = tr.num_envs, cfg.env.max_steps, cfg.env.num_defender
     W, H = cfg.map.map_size
