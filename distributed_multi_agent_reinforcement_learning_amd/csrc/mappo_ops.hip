@@ -8,7 +8,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "mappo_ops.h"
+#include "mappo_ops_diag.h"
 
 namespace {
 
@@ -681,11 +684,27 @@ __global__ __launch_bounds__(SO_TPB) void k_msg_ones_sorted_bwd(SortedArgs a, co
 }
 
 // ---- GAE ---------------------------------------------------------------------------------------------------
-__global__ void k_gae_scan(int N, int T, int P, const float *r, const float *v, const float *active, float gamma, float lamda,
-                           float *adv, float *v_target, double *stats) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// The statistics of the advantage normaliser (mean, unbiased std over all N T P elements) are f64 sums through per-workgroup
+// partials that one thread adds in index order: no atomics, so the same input gives the same bits every run (like k_ppo_loss).
+// stats: [0] sum, [1] sum of squares / of squared deviations, [2] mean, [3] std, [4 ..] the partials (2 per workgroup).
+constexpr int GAE_BLOCKS = 256;
+
+// sum over the workgroup (256 threads) of two f64 values, in a fixed order; valid in thread 0
+__device__ __forceinline__ void gae_block_sum(double &s, double &s2) {
+    __shared__ double red[2][4];
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); s2 += __shfl_xor(s2, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gae_scan(int N, int T, int P, const float *r, const float *v, const float *active, float gamma,
+                                                  float lamda, float *adv, float *v_target, double *stats) {
     double s = 0.0, s2 = 0.0;
-    if (idx < N * P) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * P; idx += gridDim.x * 256) {
         const int n = idx / P, p = idx - n * P;
         float gae = 0.f;
         for (int t = T - 1; t >= 0; t--) {
@@ -699,27 +718,39 @@ __global__ void k_gae_scan(int N, int T, int P, const float *r, const float *v, 
             s2 += (double)gae * (double)gae;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); s2 += __shfl_xor(s2, off); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], s); atomicAdd(&stats[1], s2); }
+    gae_block_sum(s, s2);
+    if (threadIdx.x == 0) { stats[4 + 2 * blockIdx.x] = s; stats[5 + 2 * blockIdx.x] = s2; }
 }
 
-__global__ void k_gae_finalize(int64_t n, double *stats) {
-    double mean = stats[0] / (double)n;
-    double var = (stats[1] - (double)n * mean * mean) / (double)(n - 1);  // unbiased, torch.std default
+__global__ void k_gae_finalize(int64_t n, int nblk, double *stats) {
+    double s = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; b++) { s += stats[4 + 2 * b]; s2 += stats[5 + 2 * b]; }
+    const double mean = s / (double)n;
+    const double var = (s2 - (double)n * mean * mean) / (double)(n - 1);  // unbiased, torch.std default (refined by k_gae_center)
+    stats[0] = s;
+    stats[1] = s2;
     stats[2] = mean;
     stats[3] = sqrt(var > 0.0 ? var : 0.0);
 }
 
-__global__ void k_gae_center(int64_t n, const float *adv, double *stats) {
+__global__ __launch_bounds__(256) void k_gae_center(int64_t n, const float *adv, double *stats) {
     // second pass for a numerically robust variance: sum (x - mean)^2
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double d = 0.0;
-    if (i < n) { double x = (double)adv[i] - stats[2]; d = x * x; }
-    for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&stats[1], d);
+    const double mean = stats[2];
+    double d = 0.0, unused = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = (double)adv[i] - mean;
+        d += x * x;
+    }
+    gae_block_sum(d, unused);
+    if (threadIdx.x == 0) stats[4 + 2 * blockIdx.x] = d;
 }
 
-__global__ void k_gae_std(int64_t n, double *stats) { stats[3] = sqrt(stats[1] / (double)(n - 1)); }
+__global__ void k_gae_std(int64_t n, int nblk, double *stats) {
+    double d = 0.0;
+    for (int b = 0; b < nblk; b++) d += stats[4 + 2 * b];
+    stats[1] = d;
+    stats[3] = sqrt(d / (double)(n - 1));
+}
 
 __global__ void k_gae_norm(int64_t n, float *adv, const float *active, const double *stats) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1235,6 +1266,31 @@ __device__ __forceinline__ f32x4 sb_mma6(const uint4 (&a)[3], const uint4 (&b)[3
     return c;
 }
 
+// test-only (include/mappo_ops_diag.h): the three pieces of every input, widened back to fp32
+__global__ void k_sb_split_diag(int64_t n, const float *__restrict__ x, float *__restrict__ pieces) {
+    const int64_t i = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const float x0 = x[i], x1 = i + 1 < n ? x[i + 1] : 0.f;
+    uint32_t p[3];
+    sb_split2(x0, x1, p[0], p[1], p[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        pieces[k * n + i] = __builtin_bit_cast(float, p[k] << 16);
+        if (i + 1 < n) pieces[k * n + i + 1] = __builtin_bit_cast(float, p[k] & 0xffff0000u);
+    }
+}
+
+// The same six products with the LARGE one (a1 b1) and the five small ones in separate accumulators.  The bf16 matrix instruction
+// aligns its 32 products to the largest exponent among them and the accumulator and truncates each with two guard bits
+// (tools/microbench/mfma_round_probe.hip; the fp32 instruction is a chain of round-to-nearest FMAs): a small piece product added to a
+// large accumulator loses up to a quarter ulp of the ACCUMULATOR.  In `lo` the small products meet an accumulator 2^-8 of the size,
+// `hi` takes one sixth of the accumulations; hi + lo is one round-to-nearest add at the end.
+__device__ __forceinline__ void sb_mma6_hl(const uint4 (&a)[3], const uint4 (&b)[3], f32x4 &hi, f32x4 &lo) {
+#define SB_MMA(i, j, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), c, 0, 0, 0);
+    SB_MMA(2, 0, lo) SB_MMA(0, 2, lo) SB_MMA(1, 1, lo) SB_MMA(0, 0, hi) SB_MMA(1, 0, lo) SB_MMA(0, 1, lo)
+#undef SB_MMA
+}
+
 #ifdef SBC_STAMP   // lab builds only (tools/microbench/gru_cell_sb_lab.hip): per-wave cycle sums of the tile loop's phases
 __device__ unsigned long long sbc_stamps[8][8];
 #define SBC_T(v) const unsigned long long v = __builtin_readcyclecounter();
@@ -1310,7 +1366,7 @@ __global__ __launch_bounds__(512) void k_gru_cell_sb(int B, int nblk, GruCellNet
     for (; blk < nblk; blk += nslots) {
         const int nxt = blk + nslots;
         const uint4 *tb = tile[cur] + l;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, lo0 = acc0, lo1 = acc0;
         SBC_T(t0)
         if (role == 0) {
 #pragma unroll
@@ -1318,20 +1374,22 @@ __global__ __launch_bounds__(512) void k_gru_cell_sb(int B, int nblk, GruCellNet
                 uint4 bx[3], bh[3];
 #pragma unroll
                 for (int p = 0; p < 3; p++) { bx[p] = tb[(p * 4 + c) * 64]; bh[p] = tb[((3 + p) * 4 + c) * 64]; }
-                acc0 = sb_mma6(wa[c], bx, acc0);
-                acc0 = sb_mma6(wb[c], bh, acc0);
-                acc1 = sb_mma6(wc[c], bx, acc1);
+                sb_mma6_hl(wa[c], bx, acc0, lo0);
+                sb_mma6_hl(wb[c], bh, acc0, lo0);
+                sb_mma6_hl(wc[c], bx, acc1, lo1);
             }
+            acc0 += lo0; acc1 += lo1;
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 uint4 bx[3], bh[3];
 #pragma unroll
                 for (int p = 0; p < 3; p++) { bx[p] = tb[(p * 4 + c) * 64]; bh[p] = tb[((3 + p) * 4 + c) * 64]; }
-                acc0 = sb_mma6(wa[c], bx, acc0);
-                acc0 = sb_mma6(wb[c], bh, acc0);
-                acc1 = sb_mma6(wc[c], bh, acc1);
+                sb_mma6_hl(wa[c], bx, acc0, lo0);
+                sb_mma6_hl(wb[c], bh, acc0, lo0);
+                sb_mma6_hl(wc[c], bh, acc1, lo1);
             }
+            acc0 += lo0; acc1 += lo1;
             xch[cur][g][0][l] = (float4){acc0[0], acc0[1], acc0[2], acc0[3]};
             xch[cur][g][1][l] = (float4){acc1[0], acc1[1], acc1[2], acc1[3]};
         }
@@ -2402,12 +2460,10 @@ template <int KC, int NT>
 int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
                    float *Y, int64_t ldy, int relu, hipStream_t st) {
     constexpr int lds = 2 * 3 * KC * 2 * 64 * 16;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_sb_gemm_n128<KC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static std::once_flag once;   // the evaluator's thread may launch concurrently with the trainer's
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [] { attr_rc = hipFuncSetAttribute((const void *)k_sb_gemm_n128<KC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+    if (attr_rc != hipSuccess) return (int)attr_rc;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const int64_t n_it = (R + 31) / 32;
@@ -2426,12 +2482,10 @@ template <int MT, int NT>
 int launch_sb_wgrad(int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *Cm, int accumulate, float *part, hipStream_t st) {
     using C = SbWgCfg<MT, NT>;
     static_assert(C::UNITS <= 512 && C::WGM * C::WGN == 8 && C::TM * C::WGM * 32 == C::M && C::TN * C::WGN * 32 == C::N && SB_DEPTH % 2 == 0, "tiling");
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_sb_wgrad<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [] { attr_rc = hipFuncSetAttribute((const void *)k_sb_wgrad<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); });
+    if (attr_rc != hipSuccess) return (int)attr_rc;
     hipLaunchKernelGGL((k_sb_wgrad<MT, NT>), dim3(SB_WGRAD_WGS), dim3(512), C::LDS_BYTES, st, A, lda, B, ldb, K, part);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((C::M * C::N + 63) / 64), dim3(256), 0, st, SB_WGRAD_WGS, C::M * C::N, (const float *)part, Cm, accumulate);
     return (int)hipGetLastError();
@@ -2585,20 +2639,20 @@ int dhgn_msg_agg_ones_sorted_bwd(int32_t R, int32_t P, int32_t K, int32_t E, con
     return (int)hipGetLastError();
 }
 
+int64_t gae_advnorm_workspace(void) { return (int64_t)(4 + 2 * GAE_BLOCKS) * sizeof(double); }
+
 int gae_advnorm(int32_t N, int32_t T, int32_t P, const float *r, const float *v, const float *active, float gamma, float lamda,
                 int32_t use_adv_norm, float *adv, float *v_target, double *stats, void *stream) {
     if (N < 1 || T < 1 || P < 1 || !r || !v || !active || !adv || !v_target || !stats) return MO_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(stats, 0, 4 * sizeof(double), s);
-    if (e != hipSuccess) return (int)e;
     const int64_t n = (int64_t)N * T * P;
-    hipLaunchKernelGGL(k_gae_scan, dim3((N * P + 255) / 256), dim3(256), 0, s, N, T, P, r, v, active, gamma, lamda, adv, v_target, stats);
+    const int64_t seq_blocks = ((int64_t)N * P + 255) / 256, el_blocks = (n + 255) / 256;
+    const int g_scan = (int)(seq_blocks < GAE_BLOCKS ? seq_blocks : GAE_BLOCKS), g_el = (int)(el_blocks < GAE_BLOCKS ? el_blocks : GAE_BLOCKS);
+    hipLaunchKernelGGL(k_gae_scan, dim3(g_scan), dim3(256), 0, s, N, T, P, r, v, active, gamma, lamda, adv, v_target, stats);
+    hipLaunchKernelGGL(k_gae_finalize, dim3(1), dim3(1), 0, s, n, g_scan, stats);
     if (use_adv_norm) {
-        hipLaunchKernelGGL(k_gae_finalize, dim3(1), dim3(1), 0, s, n, stats);
-        e = hipMemsetAsync(stats + 1, 0, sizeof(double), s);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k_gae_center, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, adv, stats);
-        hipLaunchKernelGGL(k_gae_std, dim3(1), dim3(1), 0, s, n, stats);
+        hipLaunchKernelGGL(k_gae_center, dim3(g_el), dim3(256), 0, s, n, adv, stats);
+        hipLaunchKernelGGL(k_gae_std, dim3(1), dim3(1), 0, s, n, g_el, stats);
         hipLaunchKernelGGL(k_gae_norm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, adv, active, stats);
     }
     return (int)hipGetLastError();
@@ -2740,6 +2794,12 @@ int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const 
 int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *addend,
                  int64_t lda, float *Y, int64_t ldy, void *stream) {
     return sb_gemm(R, 128, K, X, ldx, W, ldw, bias, relu, addend, lda, Y, ldy, stream);
+}
+
+int sb_split_diag(int64_t n, const float *x, float *pieces, void *stream) {
+    if (n < 1 || !x || !pieces) return MO_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_sb_split_diag, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, n, x, pieces);
+    return (int)hipGetLastError();
 }
 
 int gru_cell_fwd(int32_t B, int32_t H, const float *x, const float *h_prev, const float *w_ih, const float *w_hh, const float *b_ih,

@@ -9,6 +9,7 @@ shared by actor and critic during rollouts and the critic's all-ones
 slots in training only (Q5).
 """
 import contextlib
+import logging
 import types
 
 import numpy as np
@@ -17,6 +18,8 @@ import torch
 from . import ops
 from .model import build_actor_critic, pair_embeddings, pair_heads, sequence_forward_pair
 from .pe_env import status_or, status_text
+
+_log = logging.getLogger(__name__)
 
 BUFFER_KEYS = ("p_state", "e_state", "o_state", "p_adj", "e_adj", "o_adj", "actor_historical_embedding",
                "critic_historical_embedding", "v_n", "a_n", "a_logprob_n", "r", "active")
@@ -258,10 +261,23 @@ class MAPPO:
             self.ac_optimizer.zero_grad()
         starts = list(range(0, N, self.mini_batch_size))  # BatchSampler(SequentialSampler, mini_batch_size, drop_last=False)
         G = self._update_group(len(starts), min(self.mini_batch_size, N) * P, T)
-        if G > 1:
-            object_critics, object_actors = self._train_grouped(batch, o_static, adv, v_target, starts, G)
-            update_time = len(starts)
-            starts = []
+        while G > 1:
+            try:
+                object_critics, object_actors = self._train_grouped(batch, o_static, adv, v_target, starts, G)
+                update_time = len(starts)
+                starts = []
+                break
+            except torch.cuda.OutOfMemoryError:
+                # the estimate was too low for this device's free memory: drop the half-built graph, start the epoch over with
+                # half the group (the gradients accumulated so far are discarded; the mini-batch loop below is the G = 1 case)
+                G = self._group_limit = G // 2
+                _log.warning("update: out of device memory, retrying the epoch with %d mini-batches per autograd graph", G)
+                self.last_update_group = G
+                if getattr(self, "grad_bucket", None) is not None:
+                    self.grad_bucket.zero()
+                else:
+                    self.ac_optimizer.zero_grad()
+                torch.cuda.empty_cache()
         for n0 in starts:
             n1 = min(n0 + self.mini_batch_size, N)
             mb = n1 - n0
@@ -315,10 +331,20 @@ class MAPPO:
         if n_minibatches < 2 or not (self.actor.use_rnn and self.critic.use_rnn) or T < ops.PERSISTENT_GRU_MIN_T or self.device.type != "cuda":
             return 1
         per_minibatch = rows * T * (26e3 + 3.2e3 * self.depth)
-        cap = min(n_minibatches, ops.GRU_MULTI_MAX_NETS // 2, max(1, int(self.update_group_max_GB * 1e9 / per_minibatch)))
-        if self.update_group == "auto":
-            return cap
-        return max(1, min(int(self.update_group), cap))
+        # the budget: the configured bound, and what the device can actually give right now -- free memory plus what the caching
+        # allocator holds without using (another tenant, the background evaluator or a smaller part than the 288 GB one all show up here)
+        free, _total = torch.cuda.mem_get_info(self.device)
+        idle = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        budget = min(self.update_group_max_GB * 1e9, 0.85 * (free + idle))
+        cap = min(n_minibatches, ops.GRU_MULTI_MAX_NETS // 2, max(1, int(budget / per_minibatch)))
+        if getattr(self, "_group_limit", None):      # an earlier out-of-memory retry settled on a smaller group
+            cap = min(cap, self._group_limit)
+        G = cap if self.update_group == "auto" else max(1, min(int(self.update_group), cap))
+        if G != getattr(self, "last_update_group", None):
+            _log.info("update: %d mini-batches per autograd graph (%d mini-batches, estimate %.1f GB each, budget %.1f GB)", G, n_minibatches,
+                      per_minibatch / 1e9, budget / 1e9)
+            self.last_update_group = G
+        return G
 
     def _train_grouped(self, batch, o_static, adv, v_target, starts, G):
         """The update's mini-batches in groups of G: the weights are the same for all of them (one optimiser step per update,
@@ -489,6 +515,7 @@ class _RolloutState:
         self.graphs = {}                                      # phase (t % period) -> captured tick program
         # one encoder pass per tick for both networks (DHGN.forward_pair): they hold the same DHGN instance (:582-616)
         self.pair_forward = agent.actor.shared_net is agent.critic.shared_net
+        ops.gemm_workspace(dev)                               # this thread's hipBLASLt scratch exists before any tick program is captured
 
     @property
     def ha(self):   # the actor's current GRU state (what tick self.t reads)

@@ -13,7 +13,7 @@ from . import build as _build
 
 ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
-           "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "categorical_sample",
+           "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "gae_advnorm_workspace", "categorical_sample",
            "categorical_sample_counter",
            "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "sb_gemm", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "wgrad_split_tn", "wgrad_split_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
@@ -50,6 +50,7 @@ def load_library():
         L.dhgn_msg_agg_ones_sorted_fwd.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, i32, vp, vp, vp, i64, vp, vp, vp]
         L.dhgn_msg_agg_ones_sorted_bwd.argtypes = [i32, i32, i32, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, vp]
         L.gae_advnorm.argtypes = [i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
+        L.gae_advnorm_workspace.restype = i64
         L.categorical_sample.argtypes = [i32, i32, vp, C.c_uint64, C.c_uint64, i32, vp, vp, vp]
         L.categorical_sample_counter.argtypes = [i32, i32, vp, C.c_uint64, vp, i32, vp, vp, vp]
         L.head_linear.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
@@ -86,6 +87,7 @@ def load_library():
         L.rollout_record.argtypes = [i32, i32, vp, vp, vp, i32, vp]
         L.ppo_loss_workspace.restype = i64
         L.ppo_loss_fwd_bwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp]
+        L.sb_split_diag.argtypes = [i64, vp, vp, vp]
         L.mappo_ops_error_string.argtypes = [C.c_int]
         L.mappo_ops_error_string.restype = C.c_char_p
         _lib = L
@@ -477,7 +479,7 @@ def gae_advnorm(r, v, active, gamma, lamda, use_adv_norm=True):
     r, v, active = r.contiguous(), v.contiguous(), active.contiguous()
     adv = torch.empty_like(r)
     v_target = torch.empty_like(r)
-    stats = torch.empty(4, dtype=torch.float64, device=r.device)
+    stats = torch.empty(L.gae_advnorm_workspace() // 8, dtype=torch.float64, device=r.device)
     _check(L.gae_advnorm(N, T, P, _ptr(r), _ptr(v), _ptr(active), float(gamma), float(lamda), 1 if use_adv_norm else 0,
                          _ptr(adv), _ptr(v_target), _ptr(stats), _stream()), "gae_advnorm")
     return adv, v_target
@@ -884,6 +886,22 @@ def load_gemm_library():
     return _gemm_lib
 
 
+def gemm_workspace(device):
+    """hipBLASLt's scratch for gemm_nt: one per (device, host thread) -- a thread issues its GEMMs on one stream at a time (the trainer's
+    loop, the background evaluator's actor), so two streams never share one.  It must exist BEFORE a tick program is captured
+    (_RolloutState.__init__ calls this): memory allocated during capture belongs to that graph's private pool and must not be
+    cached beyond it."""
+    import threading
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), threading.get_ident())
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("gemm_nt: no workspace for this thread yet and the stream is capturing -- call ops.gemm_workspace(device) first")
+        ws = _gemm_ws[key] = torch.empty(load_gemm_library().mo_gemm_workspace_bytes(), dtype=torch.uint8, device=device)
+    return ws
+
+
 def gemm_nt(x, W, bias=None, relu=False, out=None, addend=None):
     """out = act(x W^T + bias + addend) for 2-D row-major x (rows, K), W (N, K), out / addend (rows, N); every matrix may be a
     column block of a wider one (last stride 1, any row stride) -- the form torch's GEMM epilogue path cannot write.  No autograd."""
@@ -898,10 +916,7 @@ def gemm_nt(x, W, bias=None, relu=False, out=None, addend=None):
         assert t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.data_ptr() % 16 == 0
     assert W.shape[1] == K and out.shape == (M, N) and (addend is None or addend.shape == (M, N))
     b = bias.detach().contiguous() if bias is not None else None
-    key = (x.device, torch.cuda.current_stream().cuda_stream)
-    ws = _gemm_ws.get(key)
-    if ws is None:
-        ws = _gemm_ws[key] = torch.empty(Lg.mo_gemm_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    ws = gemm_workspace(x.device)
     rc = Lg.mo_gemm_nt(M, N, K, _ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), _ptr(addend), addend.stride(0) if addend is not None else 0,
                        int(bool(relu)), _ptr(out), out.stride(0), _ptr(ws), ws.numel(), _stream())
     if rc != 0:

@@ -44,8 +44,12 @@ def dist_env():
 
 
 def init_distributed(backend=None):
+    """Joins the process group of a multi-rank job (one process per GPU; `nccl` = RCCL over xGMI on a GPU box, `gloo` on CPU).  A
+    single-rank job needs no group; an explicitly requested backend (argument or DMARL_DIST_BACKEND) is honoured all the same, so
+    the RCCL path -- communicator, broadcast, in-place all-reduce of the device bucket -- can be exercised on one GPU."""
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    forced = backend or os.environ.get("DMARL_DIST_BACKEND")
+    if (world > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -58,8 +62,8 @@ def init_distributed(backend=None):
 
 
 def allreduce_sum_(flat):
-    """gradient SUM over learners (main.py:121-126); no-op on one rank"""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    """gradient SUM over learners (main.py:121-126), in place; without a process group (single rank) a no-op"""
+    if dist.is_initialized():
         if flat.is_cuda and dist.get_backend() == "gloo":  # rehearsal of the N > 1 path on one GPU: stage through the host
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -67,19 +71,6 @@ def allreduce_sum_(flat):
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
-
-
-def flat_grads(params):
-    """one contiguous fp32 bucket in ac_parameters order (missing gradients count as zeros)"""
-    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-
-
-def set_flat_grads(params, flat):
-    o = 0
-    for p in params:
-        n = p.numel()
-        p.grad = flat[o:o + n].view_as(p).clone()
-        o += n
 
 
 class GradBucket:
@@ -110,7 +101,7 @@ class GradBucket:
 
 def broadcast_weights_(modules, src=0):
     """initial weight sync from learner 0 (main.py:73-75)"""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         seen = set()
         for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):
@@ -276,6 +267,9 @@ def train_agent_multiprocessing(cfg, max_iterations=None, num_eval_envs=16, eval
                 if eval_run_ref is None and if_train:
                     eval_run_ref = evaluator.run.remote(_device_weights(tr.agent.actor), _device_weights(tr.agent.critic), tr.total_steps, exp_r,
                                                         tr.last_log)
+                    if not async_eval:   # inline: this iteration's verdict and checkpoint, not the previous evaluation's
+                        if_train = collect(ray_shim.get(eval_run_ref))
+                        eval_run_ref = None
         if tr.world > 1:
             flag = torch.tensor([1 if if_train else 0], device=tr.device if dist.get_backend() != "gloo" else "cpu")
             dist.broadcast(flag, src=0)

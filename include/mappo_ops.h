@@ -125,9 +125,11 @@ int dhgn_msg_agg_ones_sorted_bwd(int32_t R, int32_t P, int32_t K, int32_t E, con
  * GAE reverse scan + value target + advantage normalisation (DHGN/mappo_parallel.py:643-658):
  *   delta = (r + gamma v[:,1:] - v[:,:-1]) * active ; gae_t = delta_t + gamma lamda gae_{t+1}
  *   v_target = adv + v[:,:-1] ; if use_adv_norm: adv = (adv - mean) / (std_unbiased + 1e-5) * active
- * r, active, adv, v_target [N][T][P]; v [N][T+1][P].  Statistics over all N*T*P elements, accumulated in f64.
- * stats (device, 4 doubles: sum, sumsq, mean, std) is scratch + output.
+ * r, active, adv, v_target [N][T][P]; v [N][T+1][P].  Statistics over all N*T*P elements, accumulated in f64 through per-workgroup
+ * partials added in index order (no atomics: the same input gives the same bits every run).
+ * stats (device, gae_advnorm_workspace() bytes; the first 4 doubles: sum, sum of squared deviations, mean, std) is scratch + output.
  */
+int64_t gae_advnorm_workspace(void);
 int gae_advnorm(int32_t N, int32_t T, int32_t P, const float *r, const float *v, const float *active, float gamma,
                 float lamda, int32_t use_adv_norm, float *adv, float *v_target, double *stats, void *stream);
 

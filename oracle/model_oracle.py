@@ -66,7 +66,8 @@ def gru_apply(sd, x, h0, num_layers=2):
     flat = []
     for layer in range(num_layers):
         flat += [sd[f"GRU.weight_ih_l{layer}"], sd[f"GRU.weight_hh_l{layer}"], sd[f"GRU.bias_ih_l{layer}"], sd[f"GRU.bias_hh_l{layer}"]]
-    out, hn = torch._VF.gru(x, h0, flat, True, num_layers, 0.0, False, False, False)
+    # (train flag: dropout is 0 either way; the GPU library's GRU only differentiates in training mode)
+    out, hn = torch._VF.gru(x, h0, flat, True, num_layers, 0.0, bool(x.is_cuda), False, False)
     return out, hn
 
 
@@ -117,7 +118,7 @@ def sequence_forward(sd, batch, hist_key, is_critic, depth, num_layers=2):
     E = emb.shape[-1]
     x = emb.permute(1, 0, 2, 3).reshape(T, N * P, E)
     H = sd["GRU.weight_hh_l0"].shape[1]
-    feat, _ = gru_apply(sd, x, torch.zeros(num_layers, N * P, H, dtype=x.dtype))
+    feat, _ = gru_apply(sd, x, torch.zeros(num_layers, N * P, H, dtype=x.dtype, device=x.device))
     feat = feat.reshape(T, N, P, H).permute(1, 0, 2, 3)
     if is_critic:
         return F.linear(feat, critic_head_weight(sd), sd["Mean.bias"]).squeeze(-1)
@@ -189,10 +190,12 @@ def ppo_losses(logp_now, entropy, values_now, batch, adv, v_target, epsilon, ent
     return actor_loss, critic_loss
 
 
-def train(sd_a, sd_c, batch, depth, mini_batch_size, gamma, lamda, epsilon, entropy_coef, clip=5.0, adv_override=None):
+def train(sd_a, sd_c, batch, depth, mini_batch_size, gamma, lamda, epsilon, entropy_coef, clip=5.0, adv_override=None, keep_grads=False):
     """MAPPO.train (:638-723) on tensors that share storage for shared_net.* between sd_a and sd_c.
     Gradients accumulate over mini-batches with clip_grad_norm_ after every backward.
-    Returns objC, objA, {name: grad} for the actor keys and for the critic keys, adv, v_target."""
+    Returns objC, objA, {name: grad} for the actor keys and for the critic keys, adv, v_target.
+    keep_grads: the tensors' existing .grad storage is accumulated into instead of being dropped first (the caller zeroed it; used by
+    the data-parallel test, whose gradients are views of one flat bucket)."""
     for k in sd_c:
         if k.startswith("shared_net."):
             sd_c[k] = sd_a[k]  # one encoder object serves both nets (MAPPO.__init__, :582-616)
@@ -206,7 +209,8 @@ def train(sd_a, sd_c, batch, depth, mini_batch_size, gamma, lamda, epsilon, entr
     leaf = [t for (who, k), t in params.items() if t.is_floating_point() and not k.endswith(("weight_u", "weight_v"))]
     for t in leaf:
         t.requires_grad_(True)
-        t.grad = None
+        if not keep_grads:
+            t.grad = None
     with torch.no_grad():
         adv, v_target = gae(batch["r"], batch["v_n"], batch["active"], gamma, lamda)
     if adv_override is not None:  # (adv, v_target) computed elsewhere, e.g. per data-parallel shard (main.py:105-129)

@@ -129,6 +129,26 @@ def test_gae_is_linear_in_rewards_at_full_size():
     assert abs(float(an.mean())) < 1e-4 and abs(float(an.std()) - 1.0) < 1e-3
 
 
+def test_gae_advnorm_is_deterministic_at_full_size():
+    """The advantage normaliser's statistics are per-workgroup f64 partials added in index order (k_gae_scan / k_gae_center; rounds
+    1-3 used f64 atomicAdd, whose order varies from launch to launch): the same input gives the same BITS every time, at the benchmark
+    batch (4096 x 150 x 8) and at a ragged size, and the statistics are those of an f64 torch evaluation (DHGN/mappo_parallel.py:643-658)."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    for (N, T, P) in ((4096, 150, 8), (1031, 37, 5)):
+        g = torch.Generator(device="cuda").manual_seed(N)
+        r = torch.randn(N, T, P, device="cuda", generator=g) * 3 + 0.5
+        v = torch.randn(N, T + 1, P, device="cuda", generator=g)
+        act = (torch.rand(N, T, P, device="cuda", generator=g) < 0.95).float()
+        first = ops.gae_advnorm(r, v, act, 0.99, 0.95, True)
+        for _ in range(5):
+            again = ops.gae_advnorm(r, v, act, 0.99, 0.95, True)
+            assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
+        raw, _ = ops.gae_advnorm(r, v, act, 0.99, 0.95, False)
+        mean, std = raw.double().mean(), raw.double().std()
+        want = ((raw.double() - mean) / (std + 1e-5) * act.double())
+        assert float((first[0].double() - want).abs().max()) < 2e-6
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("name", ["cfg2", "cfg3"])

@@ -820,23 +820,26 @@ def test_gru_step_multi_equals_separate_cells(B):
         assert outs[k].data_ptr() == hs[k][1].data_ptr()
 
 
-@pytest.mark.parametrize("K,R", [(128, 196608), (256, 65536), (384, 65536), (128, 37), (384, 1)])
-def test_split_bf16_linear_matches_f64(K, R):
-    """ops.split_linear (sb_gemm): act(x W^T + b + addend) for 128 outputs on exact three-way bf16 splits, strided operands (column
-    blocks of wider matrices), in-place accumulation; the error against f64 is that of a plain fp32 GEMM (torch.mm)."""
+@pytest.mark.parametrize("N,K,R", [(128, 128, 196608), (128, 256, 65536), (128, 384, 65536), (128, 128, 37), (128, 384, 1), (256, 128, 65536 + 5),
+                                   (384, 128, 65536 + 5), (256, 128, 31)])
+def test_split_bf16_linear_matches_f64(N, K, R):
+    """ops.split_linear (sb_gemm): act(x W^T + b + addend) for 128 / 256 / 384 outputs on exact three-way bf16 splits, strided operands
+    (column blocks of wider matrices), in-place accumulation; the error against f64 is that of a plain fp32 GEMM (torch.mm); the
+    columns of the wider output matrix outside the block are left untouched."""
     from distributed_multi_agent_reinforcement_learning_amd import ops
     old = ops.CELL_MODE
     ops.set_cell_mode("split_bf16")
     try:
-        torch.manual_seed(K + R)
+        torch.manual_seed(K + R + N)
         xw = torch.randn(R, K + 8, device="cuda")
         x = xw[:, 4:4 + K]                                   # a column block: row stride K + 8
-        Wf = torch.randn(128, K + 4, device="cuda") * 0.1
+        Wf = torch.randn(N, K + 4, device="cuda") * 0.1
         W = Wf[:, 4:]
-        b = torch.randn(128, device="cuda")
-        wide = torch.randn(R, 256, device="cuda")
-        out = wide[:, 128:]
+        b = torch.randn(N, device="cuda")
+        wide = torch.randn(R, N + 128 + 4, device="cuda")
+        out = wide[:, 128:128 + N]
         add0 = out.clone()
+        left0, right0 = wide[:, :128].clone(), wide[:, 128 + N:].clone()
         with torch.no_grad():
             assert ops.split_linear_ok(x, W, out, out)
             y = ops.split_linear(x, W, b, True, out=out, addend=out)
@@ -845,7 +848,7 @@ def test_split_bf16_linear_matches_f64(K, R):
             assert y.data_ptr() == out.data_ptr()
             e_split, e_lib = float((y.double() - ref).abs().max()), float((lib.double() - ref).abs().max())
             assert e_split <= 2.0 * e_lib + 1e-6 and e_split < 2e-5 * max(1.0, float(ref.abs().max())), (e_split, e_lib)
-            assert torch.equal(wide[:, :128], wide[:, :128])  # the left block is not touched (checked below against a copy)
+            assert torch.equal(wide[:, :128], left0) and torch.equal(wide[:, 128 + N:], right0)   # the neighbouring columns are not touched
             y2 = ops.split_linear(x, W)                          # no bias, no addend, fresh output
             assert float((y2.double() - x.double() @ W.double().t()).abs().max()) <= 2.0 * float((x @ W.t() - x.double() @ W.double().t()).abs().max()) + 1e-6
     finally:
@@ -878,3 +881,73 @@ def test_split_bf16_wgrad_is_as_accurate_as_the_fp32_wgrad(M, N):
         ops.WGRAD_MODE = old
     e_lib = float(((a.t() @ b).double() - ref).abs().max() / ref.abs().max())
     assert errs["split_bf16"] < 3e-6 and errs["split_bf16"] <= 2.0 * errs["fp32"] + 2e-7, (errs, e_lib)
+
+
+@pytest.mark.parametrize("mode", ["split_bf16", "fp32"])
+@pytest.mark.parametrize("N,K", [(128, 128), (128, 256), (128, 384), (384, 128)])
+def test_input_grad_with_strided_gradient_matches_f64(N, K, mode):
+    """ops.input_grad: g W for a Linear (N outputs, K inputs) where g is a column block of a wider matrix (the [d agg | d h] halves of
+    the FCRA backward, dgi's column slices) -- the split-bf16 route (sb_gemm on W^T) and the library route against f64."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(N + K)
+    R = 50000 + 3
+    gw = torch.randn(R, N + 132, device="cuda")
+    g = gw[:, 4:4 + N]
+    W = torch.randn(N, K, device="cuda") * 0.2
+    old = ops.PROJ_MODE
+    ops.PROJ_MODE = mode
+    try:
+        with torch.no_grad():
+            dx = ops.input_grad(g, W)
+    finally:
+        ops.PROJ_MODE = old
+    ref = g.double() @ W.double()
+    lib = (g @ W).double()
+    e, e_lib = float((dx.double() - ref).abs().max()), float((lib - ref).abs().max())
+    assert dx.shape == (R, K) and e <= 2.0 * e_lib + 1e-6, (e, e_lib)
+
+
+@pytest.mark.parametrize("mode", ["split_bf16", "fp32"])
+def test_fcra_hop_forward_and_backward_match_f64(mode):
+    """ops.fcra_hop (one DHGN.fcra hop, DHGN/mappo_parallel.py:204-233: h' = relu(FCRA([relu(AGG(nb)) | h]))) chained twice, forward
+    and every gradient against an f64 torch evaluation, at a row count above the kernels' thresholds (split-bf16 GEMMs / hipBLASLt,
+    k_relu_bwd_colsum on column blocks, k_sb_wgrad / k_wgrad).  ReLU's derivative is discontinuous: an activation within rounding
+    noise of zero may fall on either side in fp32 and f64, which moves a weight gradient by a whole row's contribution -- so the f64
+    gradients are evaluated with the ReLU masks of the product's own forward pass (read from its operand buffers)."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(3)
+    E, R, P = 128, 5000, 8
+    rows = R * P
+    mk = lambda *s: (torch.randn(*s, device="cuda") * 0.3)
+    Wa, ba, Wf, bf = [mk(E, E) for _ in range(2)], [mk(E) for _ in range(2)], [mk(E, 2 * E) for _ in range(2)], [mk(E) for _ in range(2)]
+    nb = [mk(R, P, E) for _ in range(2)]
+    h0 = mk(R, P, E)
+    gout = mk(R, P, E)
+    params = [t.clone().requires_grad_(True) for t in Wa + ba + Wf + bf]
+    cat0 = torch.empty(rows, 2 * E, device="cuda")            # hop 0's [agg | h] operand: ours, so its masks can be read afterwards
+    cat0[:, E:].copy_(h0.view(rows, E))
+    h0g = cat0.view(R, P, 2 * E)[..., E:].requires_grad_(True)
+    modes = (ops.MATMUL_MODE, ops.WGRAD_MODE, ops.PROJ_MODE, ops.CELL_MODE)
+    ops.set_matmul_mode(mode)
+    try:
+        h1, cat1 = ops.fcra_hop(nb[0], h0g, cat0, params[0], params[2], params[4], params[6], False)
+        h2, _ = ops.fcra_hop(nb[1], h1, cat1, params[1], params[3], params[5], params[7], True)
+        (h2 * gout).sum().backward()
+    finally:
+        ops.MATMUL_MODE, ops.WGRAD_MODE, ops.PROJ_MODE, ops.CELL_MODE = modes
+    masks = [(cat0[:, :E] > 0).double().view(R, P, E), (cat1[:, E:] > 0).double().view(R, P, E),
+             (cat1[:, :E] > 0).double().view(R, P, E), (h2.detach() > 0).double()]
+    p64 = [t.double().clone().requires_grad_(True) for t in Wa + ba + Wf + bf]
+    h64 = h0.double().clone().requires_grad_(True)
+    lin = torch.nn.functional.linear
+    y, y_relu = h64, h64.detach()
+    for k in range(2):
+        z_agg = lin(nb[k].double(), p64[k], p64[2 + k])
+        y = lin(torch.cat((z_agg * masks[2 * k], y), -1), p64[4 + k], p64[6 + k]) * masks[2 * k + 1]
+        with torch.no_grad():
+            y_relu = torch.relu(lin(torch.cat((torch.relu(z_agg), y_relu), -1), p64[4 + k], p64[6 + k]))
+    (y * gout.double()).sum().backward()
+    assert float((h2.detach().double() - y_relu).abs().max()) < 2e-5 * float(y_relu.abs().max())     # forward: against the plain f64 ReLU network
+    for a, b in zip(params + [h0g], p64 + [h64]):
+        scale = float(b.grad.abs().max())
+        assert float((a.grad.double() - b.grad).abs().max()) <= 3e-5 * scale + 1e-7, (a.shape, scale)
