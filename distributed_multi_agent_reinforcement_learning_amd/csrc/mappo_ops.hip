@@ -12,6 +12,7 @@
 
 #include "mappo_ops.h"
 #include "mappo_ops_diag.h"
+#include "sb_common.hpp"
 
 namespace {
 
@@ -990,17 +991,6 @@ __global__ __launch_bounds__(256) void k_head(int R, int A, const float *__restr
     }
 }
 
-// Workgroup barrier for kernels whose waves exchange data through LDS only.  __syncthreads() is a workgroup-scope release +
-// acquire around s_barrier, and the release makes every wave wait for ALL its outstanding memory operations (s_waitcnt vmcnt(0)):
-// in the persistent GRU kernels that drained 40-80 KB of freshly issued global stores per step at ~10 B/clk/CU before any wave
-// could start the next step's MFMAs (1.7 of 4.6 us per step).  Here a wave waits for its own LDS operations only; global loads
-// and stores stay in flight across the barrier and complete under the next matrix phase.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 // ---- GRU gate math (torch.nn.GRU cell; reference DHGN/mappo_parallel.py:397,424,434) ------------------------------
 // gi = x W_ih^T + b_ih and gh = h W_hh^T come from MFMA GEMMs (rocBLAS/hipBLASLt fp32); everything between them and
 // the next step's GEMM is fused here: bias, sigmoid/tanh, the state update and (for training) the saved gates.
@@ -1076,7 +1066,6 @@ __global__ void k_gru_gates_bwd(int B, int H, const float *dout, const float *dc
 // operands (96 VGPRs per lane), the h tile lives in LDS in operand order, the three gate tiles of a hidden unit land in the same
 // lane, so the gate math needs no exchange and there is one barrier per step.  Kernels: k_gru_seq_fwd2 / k_gru_seq_bwd2 below.
 constexpr int GRU_H = 128, GRU_RB = 16;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // gi_agents: row order of gi (and of dgi in the backward kernel).  0: time-major [t][b] like out.  P > 0: the rows of the
 // encoder's output, (episode n, step t, agent p) with b = n P + p, i.e. row ((b / P) T + t) P + b % P -- the input projection
@@ -1236,36 +1225,6 @@ __global__ __launch_bounds__(512) void k_gru_cell(int B, int nblk, GruCellNets n
 // per tile ~4 100 cycles of a SIMD at 1.9-2.0 GHz -- 2 300 of MFMA issue plus ~1 800 of vector work (splits, gate math with 24
 // transcendentals per lane) that in practice does not hide under the MFMAs: moving the gate math between the roles, into the next
 // tile's product phase, raising its priority or interleaving three accumulation chains each left the tile time where it was.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t sb_pk(float lo, float hi) {   // two bf16 in one dword, round to nearest even (v_cvt_pk_bf16_f32)
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-// x = p1 + p2 + p3 exactly: p1 = bf16(x); x - p1 has <= 16 significant bits and is exact in fp32; p2 = bf16(x - p1); the rest IS a bf16
-__device__ __forceinline__ void sb_split2(float x0, float x1, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
-    p1 = sb_pk(x0, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, p1 << 16), r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
-    p2 = sb_pk(r0, r1);
-    p3 = sb_pk(r0 - __builtin_bit_cast(float, p2 << 16), r1 - __builtin_bit_cast(float, p2 & 0xffff0000u));
-}
-// 8 consecutive contraction steps -> the three operand words of one lane
-__device__ __forceinline__ void sb_split8(const float4 &u, const float4 &v, uint4 (&p)[3]) {
-    sb_split2(u.x, u.y, p[0].x, p[1].x, p[2].x);
-    sb_split2(u.z, u.w, p[0].y, p[1].y, p[2].y);
-    sb_split2(v.x, v.y, p[0].z, p[1].z, p[2].z);
-    sb_split2(v.z, v.w, p[0].w, p[1].w, p[2].w);
-}
-// the six piece products of one 16 x 16 x 32 step, smallest first
-__device__ __forceinline__ f32x4 sb_mma6(const uint4 (&a)[3], const uint4 (&b)[3], f32x4 c) {
-#define SB_MMA(i, j) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), c, 0, 0, 0);
-    SB_MMA(2, 0) SB_MMA(0, 2) SB_MMA(1, 1) SB_MMA(1, 0) SB_MMA(0, 1) SB_MMA(0, 0)
-#undef SB_MMA
-    return c;
-}
-
 // test-only (include/mappo_ops_diag.h): the three pieces of every input, widened back to fp32
 __global__ void k_sb_split_diag(int64_t n, const float *__restrict__ x, float *__restrict__ pieces) {
     const int64_t i = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
@@ -1278,17 +1237,6 @@ __global__ void k_sb_split_diag(int64_t n, const float *__restrict__ x, float *_
         pieces[k * n + i] = __builtin_bit_cast(float, p[k] << 16);
         if (i + 1 < n) pieces[k * n + i + 1] = __builtin_bit_cast(float, p[k] & 0xffff0000u);
     }
-}
-
-// The same six products with the LARGE one (a1 b1) and the five small ones in separate accumulators.  The bf16 matrix instruction
-// aligns its 32 products to the largest exponent among them and the accumulator and truncates each with two guard bits
-// (tools/microbench/mfma_round_probe.hip; the fp32 instruction is a chain of round-to-nearest FMAs): a small piece product added to a
-// large accumulator loses up to a quarter ulp of the ACCUMULATOR.  In `lo` the small products meet an accumulator 2^-8 of the size,
-// `hi` takes one sixth of the accumulations; hi + lo is one round-to-nearest add at the end.
-__device__ __forceinline__ void sb_mma6_hl(const uint4 (&a)[3], const uint4 (&b)[3], f32x4 &hi, f32x4 &lo) {
-#define SB_MMA(i, j, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), c, 0, 0, 0);
-    SB_MMA(2, 0, lo) SB_MMA(0, 2, lo) SB_MMA(1, 1, lo) SB_MMA(0, 0, hi) SB_MMA(1, 0, lo) SB_MMA(0, 1, lo)
-#undef SB_MMA
 }
 
 #ifdef SBC_STAMP   // lab builds only (tools/microbench/gru_cell_sb_lab.hip): per-wave cycle sums of the tile loop's phases
@@ -1437,122 +1385,6 @@ __global__ __launch_bounds__(512) void k_gru_cell_sb(int B, int nblk, GruCellNet
 #endif
 #undef SBC_FETCH
 #undef SBC_STAGE
-}
-
-// ---- Y = act(X W^T + b [+ C]) for 128 (384) outputs, fp32 arithmetic on the bf16 matrix pipe (k_sb_gemm_n128) ------------------
-// The rollout's Linear layers (DHGN AGG / semantic / FCRA layers, reference DHGN/mappo_parallel.py:148-233: 3e4-2e5 rows against a
-// 128 x {128, 256, 384} weight; and the update's GRU input projection, 384 x 128) on the exact three-way bf16 split of k_gru_cell_sb.
-// Persistent workgroups; wave w keeps output units 16 (w + 8 t) .. + 15 of W as A-operands (12 registers per 32 inputs and tile, split once); 32 rows per iteration stream through a
-// double-buffered LDS image: a wave stages (chunk, half) blocks -- lane (gq, j) loads the 8 inputs 32 c + 8 gq .. of row j (16 rows
-// x 128 contiguous bytes per instruction), splits them and writes one 16-byte word per piece, which IS lane (j, gq)'s B-operand.
-// The result tile has a lane own four consecutive outputs of one row: bias, the optional addend (may be Y itself: beta = 1) and
-// ReLU in registers, one 16-byte store.  X, C and Y may be column blocks of wider matrices (row strides).
-template <int KC, int NT>   // inputs / 32, outputs / 128
-__global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__restrict__ X, int64_t ldx, const float *__restrict__ W, int64_t ldw,
-                                                      const float *__restrict__ bias, const float *addend, int64_t lda, float *Y, int64_t ldy, int relu) {
-    extern __shared__ uint4 sbg_tile[];                 // [buffer][piece][chunk][row half][lane]
-    constexpr int IMG = 3 * KC * 2 * 64, UPW = KC / 4;  // uint4 per image; (chunk, half) blocks staged per wave and iteration
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, gq = l >> 4;
-    uint4 wg[NT][KC][3];                                // output tiles w, w + 8, .. (16 outputs each)
-    float4 b4[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const float *rw = W + (size_t)(16 * (w + 8 * t) + i) * ldw + 8 * gq;
-#pragma unroll
-        for (int c = 0; c < KC; c++) sb_split8(*(const float4 *)(rw + 32 * c), *(const float4 *)(rw + 32 * c + 4), wg[t][c]);
-        b4[t] = bias ? *(const float4 *)(bias + 16 * (w + 8 * t) + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int64_t n_it = (R + 31) / 32;
-    float4 pf[UPW][2];
-    auto fetch = [&](int64_t it) {
-#pragma unroll
-        for (int n = 0; n < UPW; n++) {
-            const int blk = w * UPW + n, c = blk >> 1, rt = blk & 1;      // this wave's n-th (chunk, half) block
-            const int64_t row = it * 32 + rt * 16 + i;
-            pf[n][0] = pf[n][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < R) {
-                const float *src = X + row * ldx + 32 * c + 8 * gq;
-                pf[n][0] = *(const float4 *)src;
-                pf[n][1] = *(const float4 *)(src + 4);
-            }
-        }
-    };
-    auto stage = [&](uint4 *img) {
-#pragma unroll
-        for (int n = 0; n < UPW; n++) {
-            const int blk = w * UPW + n;
-            uint4 p_[3];
-            sb_split8(pf[n][0], pf[n][1], p_);
-#pragma unroll
-            for (int p = 0; p < 3; p++) img[(p * KC * 2 + blk) * 64 + l] = p_[p];
-        }
-    };
-    int64_t it = blockIdx.x;
-    if (it < n_it) { fetch(it); stage(sbg_tile); }
-    if (it + gridDim.x < n_it) fetch(it + gridDim.x);
-    lds_barrier();
-    int cur = 0;
-    for (; it < n_it; it += gridDim.x) {
-        const uint4 *tb = sbg_tile + cur * IMG + l;
-        f32x4 acc[NT][2];
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t][0] = acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // the operands of chunk c + 1 are read while chunk c is multiplied (pinned with scheduling barriers: left alone, the compiler
-        // issues a chunk's reads after the previous chunk's MFMAs and the matrix pipe drains behind every LDS round trip)
-        // (the HBM-bound 128 x 128 variant is better off without: 106 against 114 us at 492 000 rows)
-        constexpr bool AHEAD = KC * NT > 4;
-        uint4 nb0[3], nb1[3];
-        if constexpr (AHEAD) {
-#pragma unroll
-            for (int p = 0; p < 3; p++) { nb0[p] = tb[(p * KC * 2) * 64]; nb1[p] = tb[(p * KC * 2 + 1) * 64]; }
-        }
-#pragma unroll
-        for (int c = 0; c < KC; c++) {
-            uint4 b0[3], b1[3];
-            if constexpr (AHEAD) {
-#pragma unroll
-                for (int p = 0; p < 3; p++) { b0[p] = nb0[p]; b1[p] = nb1[p]; }
-                if (c + 1 < KC) {
-#pragma unroll
-                    for (int p = 0; p < 3; p++) { nb0[p] = tb[(p * KC * 2 + 2 * c + 2) * 64]; nb1[p] = tb[(p * KC * 2 + 2 * c + 3) * 64]; }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-#pragma unroll
-                for (int p = 0; p < 3; p++) { b0[p] = tb[(p * KC * 2 + 2 * c) * 64]; b1[p] = tb[(p * KC * 2 + 2 * c + 1) * 64]; }
-            }
-#define SBG_MMA(pi, pj)                                                                                                                             \
-            _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                                                          \
-                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b0[pj]), acc[t][0], 0, 0, 0); \
-                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b1[pj]), acc[t][1], 0, 0, 0); \
-            }
-            SBG_MMA(2, 0) SBG_MMA(0, 2) SBG_MMA(1, 1) SBG_MMA(1, 0) SBG_MMA(0, 1) SBG_MMA(0, 0)
-#undef SBG_MMA
-            if constexpr (AHEAD) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (it + gridDim.x < n_it) stage(sbg_tile + (cur ^ 1) * IMG);          // the rows fetched one iteration ago -> the other image
-        if (it + 2 * (int64_t)gridDim.x < n_it) fetch(it + 2 * (int64_t)gridDim.x);
-        // D tile: lane (i, gq), register q -> output 16 (w + 8 t) + 4 gq + q of row i of the half
-#pragma unroll
-        for (int rt = 0; rt < 2; rt++) {
-            const int64_t row = it * 32 + rt * 16 + i;
-            if (row < R) {
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const int col = 16 * (w + 8 * t) + 4 * gq;
-                    float4 v = make_float4(acc[t][rt][0] + b4[t].x, acc[t][rt][1] + b4[t].y, acc[t][rt][2] + b4[t].z, acc[t][rt][3] + b4[t].w);
-                    if (addend) {
-                        const float4 a4 = *(const float4 *)(addend + row * lda + col);
-                        v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
-                    }
-                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    *(float4 *)(Y + row * ldy + col) = v;
-                }
-            }
-        }
-        lds_barrier();
-        cur ^= 1;
-    }
 }
 
 // ---- the sequence kernels: TRANSPOSED tiles ------------------------------------------------------------------------------------
@@ -2042,15 +1874,6 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(int S, int MN, const float
     }
 }
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// the six piece products of one 32 x 32 x 16 tile step, smallest first
-__device__ __forceinline__ f32x16 sb_mma6_32(const uint4 (&a)[3], const uint4 (&b)[3], f32x16 c) {
-#define SB_MMA(i, j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), c, 0, 0, 0);
-    SB_MMA(2, 0) SB_MMA(0, 2) SB_MMA(1, 1) SB_MMA(1, 0) SB_MMA(0, 1) SB_MMA(0, 0)
-#undef SB_MMA
-    return c;
-}
-
 // ---- weight gradient  C[M][N] = A^T B in the split arithmetic (k_sb_wgrad; A [K][M], B [K][N], K ~ 5e5 rows) ---------------------
 // One workgroup (8 waves, two per SIMD: one wave's splitting runs under the other's MFMAs) owns the WHOLE M x N output in its
 // accumulators and a contiguous range of the rows (split-K, partials reduced in a fixed order afterwards).  Rows arrive in chunks
@@ -2456,22 +2279,6 @@ int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int
 
 }  // namespace
 
-template <int KC, int NT>
-int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
-                   float *Y, int64_t ldy, int relu, hipStream_t st) {
-    constexpr int lds = 2 * 3 * KC * 2 * 64 * 16;
-    static std::once_flag once;   // the evaluator's thread may launch concurrently with the trainer's
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [] { attr_rc = hipFuncSetAttribute((const void *)k_sb_gemm_n128<KC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-    if (attr_rc != hipSuccess) return (int)attr_rc;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const int64_t n_it = (R + 31) / 32;
-    const int grid = n_it < cus ? (int)n_it : cus;
-    hipLaunchKernelGGL((k_sb_gemm_n128<KC, NT>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu);
-    return (int)hipGetLastError();
-}
-
 constexpr int SB_WGRAD_WGS = 256;  // one workgroup per CU (96 KB of LDS each)
 
 static bool sb_wgrad_shape_ok(int M, int N) {
@@ -2773,27 +2580,6 @@ int gru_cell_split_fwd_multi(int32_t n_nets, const mo_gru_cell_net *nets, int32_
     if (pairs > nblk) pairs = nblk;
     hipLaunchKernelGGL(k_gru_cell_sb, dim3(2 * pairs, n_nets), dim3(512), 0, (hipStream_t)stream, (int)B, nblk, a);
     return (int)hipGetLastError();
-}
-
-int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu,
-            const float *addend, int64_t lda, float *Y, int64_t ldy, void *stream) {
-    if (R < 0 || !X || !W || !Y || ldx < K || ldw < K || ldy < N || (addend && lda < N)) return MO_ERR_BAD_ARG;
-    if ((ldx & 3) || (ldw & 3) || (ldy & 3) || (lda & 3) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)addend & 15) ||
-        ((uintptr_t)bias & 15))
-        return MO_ERR_BAD_ARG;
-    if (R == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (N == 128 && K == 128) return launch_sb_gemm<4, 1>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
-    if (N == 128 && K == 256) return launch_sb_gemm<8, 1>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
-    if (N == 128 && K == 384) return launch_sb_gemm<12, 1>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
-    if (N == 256 && K == 128) return launch_sb_gemm<4, 2>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
-    if (N == 384 && K == 128) return launch_sb_gemm<4, 3>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
-    return MO_ERR_BAD_ARG;
-}
-
-int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *addend,
-                 int64_t lda, float *Y, int64_t ldy, void *stream) {
-    return sb_gemm(R, 128, K, X, ldx, W, ldw, bias, relu, addend, lda, Y, ldy, stream);
 }
 
 int sb_split_diag(int64_t n, const float *x, float *pieces, void *stream) {

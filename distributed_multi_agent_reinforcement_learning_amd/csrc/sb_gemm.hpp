@@ -1,0 +1,168 @@
+// sb_gemm.hpp -- Linear layers in fp32 arithmetic on the bf16 matrix pipe (C ABI: include/mappo_ops.h sb_gemm)
+#pragma once
+#include <mutex>
+
+#include "sb_common.hpp"
+
+// ---- Y = act(X W^T + b [+ C]) for 128 (384) outputs, fp32 arithmetic on the bf16 matrix pipe (k_sb_gemm_n128) ------------------
+// The rollout's Linear layers (DHGN AGG / semantic / FCRA layers, reference DHGN/mappo_parallel.py:148-233: 3e4-2e5 rows against a
+// 128 x {128, 256, 384} weight; and the update's GRU input projection, 384 x 128) on the exact three-way bf16 split of k_gru_cell_sb.
+// Persistent workgroups; wave w keeps output units 16 (w + 8 t) .. + 15 of W as A-operands (12 registers per 32 inputs and tile, split once); 32 rows per iteration stream through a
+// double-buffered LDS image: a wave stages (chunk, half) blocks -- lane (gq, j) loads the 8 inputs 32 c + 8 gq .. of row j (16 rows
+// x 128 contiguous bytes per instruction), splits them and writes one 16-byte word per piece, which IS lane (j, gq)'s B-operand.
+// The result tile has a lane own four consecutive outputs of one row: bias, the optional addend (may be Y itself: beta = 1) and
+// ReLU in registers, one 16-byte store.  X, C and Y may be column blocks of wider matrices (row strides).
+// OPT (bit mask; the product launches 3): 1 = the addend rows of a tile are requested BEFORE its matrix phase (round 3 loaded them
+// in the epilogue: one exposed HBM latency per 32 rows, 138 us against 47 us for the rollout's in-place semantic layer at 65 536
+// rows); 2 = the two waves of a SIMD (w and w + 4) run out of phase -- one splits and stages the next tile while the other
+// multiplies, as in k_sb_wgrad -- instead of all eight waves staging, then all multiplying.
+template <int KC, int NT, int OPT = 3>   // inputs / 32, outputs / 128
+__global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__restrict__ X, int64_t ldx, const float *__restrict__ W, int64_t ldw,
+                                                      const float *__restrict__ bias, const float *addend, int64_t lda, float *Y, int64_t ldy, int relu) {
+    extern __shared__ uint4 sbg_tile[];                 // [buffer][piece][chunk][row half][lane]
+    constexpr int IMG = 3 * KC * 2 * 64, UPW = KC / 4;  // uint4 per image; (chunk, half) blocks staged per wave and iteration
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, gq = l >> 4;
+    uint4 wg[NT][KC][3];                                // output tiles w, w + 8, .. (16 outputs each)
+    float4 b4[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float *rw = W + (size_t)(16 * (w + 8 * t) + i) * ldw + 8 * gq;
+#pragma unroll
+        for (int c = 0; c < KC; c++) sb_split8(*(const float4 *)(rw + 32 * c), *(const float4 *)(rw + 32 * c + 4), wg[t][c]);
+        b4[t] = bias ? *(const float4 *)(bias + 16 * (w + 8 * t) + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int64_t n_it = (R + 31) / 32;
+    float4 pf[UPW][2];
+    auto fetch = [&](int64_t it) {
+#pragma unroll
+        for (int n = 0; n < UPW; n++) {
+            const int blk = w * UPW + n, c = blk >> 1, rt = blk & 1;      // this wave's n-th (chunk, half) block
+            const int64_t row = it * 32 + rt * 16 + i;
+            pf[n][0] = pf[n][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < R) {
+                const float *src = X + row * ldx + 32 * c + 8 * gq;
+                pf[n][0] = *(const float4 *)src;
+                pf[n][1] = *(const float4 *)(src + 4);
+            }
+        }
+    };
+    auto stage = [&](uint4 *img) {
+#pragma unroll
+        for (int n = 0; n < UPW; n++) {
+            const int blk = w * UPW + n;
+            uint4 p_[3];
+            sb_split8(pf[n][0], pf[n][1], p_);
+#pragma unroll
+            for (int p = 0; p < 3; p++) img[(p * KC * 2 + blk) * 64 + l] = p_[p];
+        }
+    };
+    int64_t it = blockIdx.x;
+    if (it < n_it) { fetch(it); stage(sbg_tile); }
+    if (it + gridDim.x < n_it) fetch(it + gridDim.x);
+    lds_barrier();
+    int cur = 0;
+    for (; it < n_it; it += gridDim.x) {
+        const uint4 *tb = sbg_tile + cur * IMG + l;
+        f32x4 acc[NT][2];
+        float4 a4[NT][2];
+        if ((OPT & 1) && addend) {   // in flight during the matrix phase
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) {
+                const int64_t row = it * 32 + rt * 16 + i;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    a4[t][rt] = row < R ? *(const float4 *)(addend + row * lda + 16 * (w + 8 * t) + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        auto next_tile = [&]() {
+            if (it + gridDim.x < n_it) stage(sbg_tile + (cur ^ 1) * IMG);          // the rows fetched one iteration ago -> the other image
+            if (it + 2 * (int64_t)gridDim.x < n_it) fetch(it + 2 * (int64_t)gridDim.x);
+        };
+        if ((OPT & 2) && w < 4) next_tile();
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t][0] = acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the operands of chunk c + 1 are read while chunk c is multiplied (pinned with scheduling barriers: left alone, the compiler
+        // issues a chunk's reads after the previous chunk's MFMAs and the matrix pipe drains behind every LDS round trip)
+        // (the HBM-bound 128 x 128 variant is better off without: 106 against 114 us at 492 000 rows)
+        constexpr bool AHEAD = KC * NT > 4;
+        uint4 nb0[3], nb1[3];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int p = 0; p < 3; p++) { nb0[p] = tb[(p * KC * 2) * 64]; nb1[p] = tb[(p * KC * 2 + 1) * 64]; }
+        }
+#pragma unroll
+        for (int c = 0; c < KC; c++) {
+            uint4 b0[3], b1[3];
+            if constexpr (AHEAD) {
+#pragma unroll
+                for (int p = 0; p < 3; p++) { b0[p] = nb0[p]; b1[p] = nb1[p]; }
+                if (c + 1 < KC) {
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { nb0[p] = tb[(p * KC * 2 + 2 * c + 2) * 64]; nb1[p] = tb[(p * KC * 2 + 2 * c + 3) * 64]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 3; p++) { b0[p] = tb[(p * KC * 2 + 2 * c) * 64]; b1[p] = tb[(p * KC * 2 + 2 * c + 1) * 64]; }
+            }
+#define SBG_MMA(pi, pj)                                                                                                                             \
+            _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                                                          \
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b0[pj]), acc[t][0], 0, 0, 0); \
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b1[pj]), acc[t][1], 0, 0, 0); \
+            }
+            SBG_MMA(2, 0) SBG_MMA(0, 2) SBG_MMA(1, 1) SBG_MMA(1, 0) SBG_MMA(0, 1) SBG_MMA(0, 0)
+#undef SBG_MMA
+            if constexpr (AHEAD) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(OPT & 2) || w >= 4) next_tile();
+        // D tile: lane (i, gq), register q -> output 16 (w + 8 t) + 4 gq + q of row i of the half
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            const int64_t row = it * 32 + rt * 16 + i;
+            if (row < R) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int col = 16 * (w + 8 * t) + 4 * gq;
+                    float4 v = make_float4(acc[t][rt][0] + b4[t].x, acc[t][rt][1] + b4[t].y, acc[t][rt][2] + b4[t].z, acc[t][rt][3] + b4[t].w);
+                    if (addend) {
+                        if (!(OPT & 1)) a4[t][rt] = *(const float4 *)(addend + row * lda + col);
+                        v.x += a4[t][rt].x; v.y += a4[t][rt].y; v.z += a4[t][rt].z; v.w += a4[t][rt].w;
+                    }
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *(float4 *)(Y + row * ldy + col) = v;
+                }
+            }
+        }
+        lds_barrier();
+        cur ^= 1;
+    }
+}
+
+template <int KC, int NT, int OPT>
+int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
+                   float *Y, int64_t ldy, int relu, hipStream_t st) {
+    constexpr int lds = 2 * 3 * KC * 2 * 64 * 16;
+    static std::once_flag once;   // the evaluator's thread may launch concurrently with the trainer's
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [] { attr_rc = hipFuncSetAttribute((const void *)k_sb_gemm_n128<KC, NT, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+    if (attr_rc != hipSuccess) return (int)attr_rc;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int64_t n_it = (R + 31) / 32;
+    const int grid = n_it < cus ? (int)n_it : cus;
+    hipLaunchKernelGGL((k_sb_gemm_n128<KC, NT, OPT>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu);
+    return (int)hipGetLastError();
+}
+
+// Which OPT per shape, plain / with an addend (tools/microbench/sb_gemm_lab.hip, 492 000 rows, us; profiles/r04_sb_gemm_lab.txt):
+//   128 <- 384: 366 / 416 (OPT 0) -> 298 / 391 (OPT 2);   128 <- 256: 253 / 315 -> 213 (OPT 2) / 277 (OPT 3);   128 <- 128: 123 (OPT 0) /
+//   210 -> 180 (OPT 1);   256 <- 128: 263 / 363 -> 223 (OPT 2) / 311 (OPT 1);   384 <- 128: 363 / 516 -> 310 (OPT 2) / 516 (OPT 0).
+// The early addend request costs registers the 384-input and 384-output variants do not have (it spills there).
+template <int KC, int NT>
+int launch_sb_gemm_best(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
+                        float *Y, int64_t ldy, int relu, hipStream_t st) {
+    constexpr int PLAIN = (KC == 4 && NT == 1) ? 0 : 2;
+    constexpr int ADD = KC == 12 ? 2 : (KC == 8 ? 3 : (NT == 3 ? 0 : 1));
+    if (addend) return launch_sb_gemm<KC, NT, ADD>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+    return launch_sb_gemm<KC, NT, PLAIN>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+}
