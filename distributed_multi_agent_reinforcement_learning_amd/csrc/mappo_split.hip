@@ -6,6 +6,7 @@
 
 #include "mappo_ops.h"
 #include "sb_gemm.hpp"
+#include "sb_gru_seq.hpp"
 
 extern "C" {
 
@@ -28,6 +29,31 @@ int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const 
 int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *addend,
                  int64_t lda, float *Y, int64_t ldy, void *stream) {
     return sb_gemm(R, 128, K, X, ldx, W, ldw, bias, relu, addend, lda, Y, ldy, stream);
+}
+
+int gru_seq_split_fwd_multi(int32_t n_nets, const mo_gru_seq_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream) {
+    if (n_nets < 1 || n_nets > MO_GRU_MAX_NETS || !nets || T < 1 || B < 1 || H != SBR_H || gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
+    for (int k = 0; k < n_nets; k++) {
+        const mo_gru_seq_net &m = nets[k];
+        if (!m.gi || !m.w_hh || !m.b_hh || !m.h0 || !m.out) return MO_ERR_BAD_ARG;
+        if ((((uintptr_t)m.gi | (uintptr_t)m.w_hh | (uintptr_t)m.b_hh | (uintptr_t)m.h0 | (uintptr_t)m.out | (uintptr_t)m.save) & 15)) return MO_ERR_BAD_ARG;
+        if (m.B < 0 || m.B > B || (gi_agents && m.B % gi_agents)) return MO_ERR_BAD_ARG;
+    }
+    return launch_gru_seq_fwd_sb(n_nets, nets, T, B, gi_agents, (hipStream_t)stream);
+}
+
+int gru_seq_split_bwd_multi(int32_t n_nets, const mo_gru_seq_bwd_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream) {
+    if (n_nets < 1 || n_nets > MO_GRU_MAX_NETS || !nets || T < 1 || B < 1 || H != SBR_H || gi_agents < 0 || (gi_agents && B % gi_agents)) return MO_ERR_BAD_ARG;
+    for (int k = 0; k < n_nets; k++) {
+        const mo_gru_seq_bwd_net &m = nets[k];
+        if (!m.dout || !m.save || !m.out || !m.h0 || !m.w_hh || !m.dgi || !m.dh0) return MO_ERR_BAD_ARG;
+        if ((m.dgh == nullptr) == (m.dnr == nullptr)) return MO_ERR_BAD_ARG;        // exactly one of the two forms
+        if ((m.db_ih || m.db_hh) && (!m.db_ih || !m.db_hh || !m.workspace)) return MO_ERR_BAD_ARG;
+        if ((((uintptr_t)m.dout | (uintptr_t)m.save | (uintptr_t)m.out | (uintptr_t)m.h0 | (uintptr_t)m.dgi | (uintptr_t)m.dgh | (uintptr_t)m.dnr |
+              (uintptr_t)m.dh0 | (uintptr_t)m.workspace) & 15)) return MO_ERR_BAD_ARG;
+        if (m.B < 0 || m.B > B || (gi_agents && m.B % gi_agents)) return MO_ERR_BAD_ARG;
+    }
+    return launch_gru_seq_bwd_sb(n_nets, nets, T, B, gi_agents, (hipStream_t)stream);
 }
 
 }  // extern "C"

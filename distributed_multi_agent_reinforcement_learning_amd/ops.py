@@ -15,7 +15,7 @@ ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "gae_advnorm_workspace", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "sb_gemm", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "wgrad_split_tn", "wgrad_split_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "sb_gemm", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_split_fwd_multi", "gru_seq_split_bwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "wgrad_split_tn", "wgrad_split_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -66,6 +66,8 @@ def load_library():
         L.sb_gemm.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp, i64, vp]
         L.gru_seq_fwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_bwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
+        L.gru_seq_split_fwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
+        L.gru_seq_split_bwd_multi.argtypes = [i32, vp, i32, i32, i32, i32, vp]
         L.gru_seq_save_elems.argtypes = [i32, i32]
         L.gru_seq_save_elems.restype = i64
         L.gru_seq_bwd_workspace.argtypes = [i32]
@@ -1062,6 +1064,23 @@ def rollout_record(pairs, raw=None, episode_return=None):
 
 
 PERSISTENT_GRU_MIN_T = 2  # sequences at least this long take the one-launch recurrence (H = 128)
+# the persistent recurrences of the update: "fp32" = k_gru_seq_fwd2 / bwd2 (v_mfma_f32_16x16x4_f32), "split_bf16" = the same arithmetic
+# from exact three-way bf16 operand splits (csrc/sb_gru_seq.hpp); interchangeable save layout.  Follows `runtime.matmul`.
+SEQ_MODE = os.environ.get("MAPPO_GRU_SEQ", os.environ.get("MAPPO_MATMUL", "split_bf16"))
+
+
+def _seq_fwd(L, arr, n, T, Bmax, H, agents):
+    if SEQ_MODE == "split_bf16":
+        _check(L.gru_seq_split_fwd_multi(n, C.cast(arr, C.c_void_p), T, Bmax, H, agents, _stream()), "gru_seq_split_fwd_multi")
+    else:
+        _check(L.gru_seq_fwd_multi(n, C.cast(arr, C.c_void_p), T, Bmax, H, agents, _stream()), "gru_seq_fwd_multi")
+
+
+def _seq_bwd(L, arr, n, T, Bmax, H, agents):
+    if SEQ_MODE == "split_bf16":
+        _check(L.gru_seq_split_bwd_multi(n, C.cast(arr, C.c_void_p), T, Bmax, H, agents, _stream()), "gru_seq_split_bwd_multi")
+    else:
+        _check(L.gru_seq_bwd_multi(n, C.cast(arr, C.c_void_p), T, Bmax, H, agents, _stream()), "gru_seq_bwd_multi")
 
 
 class _GRULayer(torch.autograd.Function):
@@ -1097,10 +1116,14 @@ class _GRULayer(torch.autograd.Function):
         b_hh = b_hh.contiguous()
         st = _stream()
         ctx.persistent, ctx.dims, ctx.agents = persistent, (T, B, I), int(agents)
-        if persistent:  # whole recurrence in one launch, W_hh in registers (csrc/mappo_ops.hip k_gru_seq_fwd)
+        if persistent:  # whole recurrence in one launch, W_hh in registers (csrc/mappo_ops.hip k_gru_seq_fwd2 | csrc/sb_gru_seq.hpp)
             whh = w_hh.detach().contiguous()
-            _check(L.gru_seq_fwd(T, B, H, _ptr(gi), _ptr(whh), _ptr(b_hh), _ptr(h0), _ptr(out), _ptr(save) if need else None, int(agents), st),
-                   "gru_seq_fwd")
+            arr = (GruSeqNet * 1)()
+            a = arr[0]
+            a.gi, a.w_hh, a.b_hh, a.h0, a.out = gi.data_ptr(), whh.data_ptr(), b_hh.data_ptr(), h0.data_ptr(), out.data_ptr()
+            a.save = save.data_ptr() if need else None
+            a.B = B
+            _seq_fwd(L, arr, 1, T, B, H, int(agents))
             if need:
                 ctx.save_for_backward(x, h0, w_ih, whh, out, save)
             return out
@@ -1138,8 +1161,14 @@ class _GRULayer(torch.autograd.Function):
             db_ih = torch.empty(3 * H, dtype=x.dtype, device=x.device)
             db_hh = torch.empty(3 * H, dtype=x.dtype, device=x.device)
             ws = torch.empty(L.gru_seq_bwd_workspace(B), dtype=torch.uint8, device=x.device)
-            _check(L.gru_seq_bwd(T, B, H, _ptr(dout), _ptr(save), _ptr(out), _ptr(h0), _ptr(w_hh), _ptr(dgi), _ptr(dgh), _ptr(dnr), _ptr(dh_direct),
-                                 _ptr(db_ih), _ptr(db_hh), ctx.agents, _ptr(ws), st), "gru_seq_bwd")
+            arr = (GruSeqBwdNet * 1)()
+            a = arr[0]
+            a.dout, a.save, a.out, a.h0, a.w_hh, a.dgi = dout.data_ptr(), save.data_ptr(), out.data_ptr(), h0.data_ptr(), w_hh.data_ptr(), dgi.data_ptr()
+            a.dgh = dgh.data_ptr() if dgh is not None else None
+            a.dnr = dnr.data_ptr() if dnr is not None else None
+            a.dh0, a.db_ih, a.db_hh, a.workspace = dh_direct.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), ws.data_ptr()
+            a.B = B
+            _seq_bwd(L, arr, 1, T, B, H, ctx.agents)
             dcarry = dh_direct
         else:
             dgi3 = dgi.view(T, B, 3 * H)
@@ -1181,11 +1210,21 @@ def set_cell_mode(mode):
     CELL_MODE = mode
 
 
+def matmul_modes():
+    """the five switches set_matmul_mode() sets together (tests and A/B tools save and restore them)"""
+    return MATMUL_MODE, WGRAD_MODE, PROJ_MODE, CELL_MODE, SEQ_MODE
+
+
+def restore_matmul_modes(modes):
+    global MATMUL_MODE, WGRAD_MODE, PROJ_MODE, CELL_MODE, SEQ_MODE
+    MATMUL_MODE, WGRAD_MODE, PROJ_MODE, CELL_MODE, SEQ_MODE = modes
+
+
 def set_matmul_mode(mode):
     """all three parts at once (`runtime.matmul`)"""
-    global MATMUL_MODE, WGRAD_MODE, PROJ_MODE
+    global MATMUL_MODE, WGRAD_MODE, PROJ_MODE, SEQ_MODE
     set_cell_mode(mode)
-    MATMUL_MODE = WGRAD_MODE = PROJ_MODE = mode
+    MATMUL_MODE = WGRAD_MODE = PROJ_MODE = SEQ_MODE = mode
 
 
 SPLIT_LINEAR_SHAPES = {(128, 128), (128, 256), (128, 384), (256, 128), (384, 128)}    # (outputs, inputs) sb_gemm covers
@@ -1319,7 +1358,7 @@ class _GRULayerMulti(torch.autograd.Function):
             keep.append((gi, whh, bhh))
             outs.append(out)
             saved += [x, h0, w_ih, whh, out, save]
-        _check(L.gru_seq_fwd_multi(n, C.cast(arr, C.c_void_p), T, max(Bs), H, int(agents), _stream()), "gru_seq_fwd_multi")
+        _seq_fwd(L, arr, n, T, max(Bs), H, int(agents))
         ctx.dims, ctx.agents, ctx.n = (T, tuple(Bs)), int(agents), n
         ctx.x_shapes = [ts[6 * k].shape for k in range(n)]
         if need:
@@ -1353,7 +1392,7 @@ class _GRULayerMulti(torch.autograd.Function):
             a.dh0, a.db_ih, a.db_hh, a.workspace = dh0.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), ws.data_ptr()
             a.B = B
             per.append((dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws))
-        _check(L.gru_seq_bwd_multi(n, C.cast(arr, C.c_void_p), T, max(Bs), H, ctx.agents, _stream()), "gru_seq_bwd_multi")
+        _seq_bwd(L, arr, n, T, max(Bs), H, ctx.agents)
         grads = [None, None, None]
         for k in range(n):
             x, h0, w_ih, w_hh, out, save = sv[6 * k: 6 * k + 6]

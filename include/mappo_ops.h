@@ -212,6 +212,10 @@ typedef struct mo_gru_seq_bwd_net {
 } mo_gru_seq_bwd_net;
 int gru_seq_fwd_multi(int32_t n_nets, const mo_gru_seq_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream);
 int gru_seq_bwd_multi(int32_t n_nets, const mo_gru_seq_bwd_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream);
+/* The same recurrences in fp32 arithmetic on the bf16 matrix pipe (exact three-way operand splits, csrc/sb_gru_seq.hpp): same records,
+ * same (interchangeable) save layout, results equal to the fp32-MFMA kernels' to fp32 rounding.  `runtime.matmul: split_bf16`. */
+int gru_seq_split_fwd_multi(int32_t n_nets, const mo_gru_seq_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream);
+int gru_seq_split_bwd_multi(int32_t n_nets, const mo_gru_seq_bwd_net *nets, int32_t T, int32_t B, int32_t H, int32_t gi_agents, void *stream);
 int gru_seq_fwd(int32_t T, int32_t B, int32_t H, const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *out,
                 float *save, int32_t gi_agents, void *stream);
 int64_t gru_seq_bwd_workspace(int32_t B);

@@ -927,14 +927,14 @@ def test_fcra_hop_forward_and_backward_match_f64(mode):
     cat0 = torch.empty(rows, 2 * E, device="cuda")            # hop 0's [agg | h] operand: ours, so its masks can be read afterwards
     cat0[:, E:].copy_(h0.view(rows, E))
     h0g = cat0.view(R, P, 2 * E)[..., E:].requires_grad_(True)
-    modes = (ops.MATMUL_MODE, ops.WGRAD_MODE, ops.PROJ_MODE, ops.CELL_MODE)
+    modes = ops.matmul_modes()
     ops.set_matmul_mode(mode)
     try:
         h1, cat1 = ops.fcra_hop(nb[0], h0g, cat0, params[0], params[2], params[4], params[6], False)
         h2, _ = ops.fcra_hop(nb[1], h1, cat1, params[1], params[3], params[5], params[7], True)
         (h2 * gout).sum().backward()
     finally:
-        ops.MATMUL_MODE, ops.WGRAD_MODE, ops.PROJ_MODE, ops.CELL_MODE = modes
+        ops.restore_matmul_modes(modes)
     masks = [(cat0[:, :E] > 0).double().view(R, P, E), (cat1[:, E:] > 0).double().view(R, P, E),
              (cat1[:, :E] > 0).double().view(R, P, E), (h2.detach() > 0).double()]
     p64 = [t.double().clone().requires_grad_(True) for t in Wa + ba + Wf + bf]

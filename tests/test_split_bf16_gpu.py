@@ -230,3 +230,73 @@ def test_split_cell_on_adversarial_operands(case):
             ops.set_cell_mode(old)
     _record(test="gru_cell", case=case, rows=B, err_split=errs["split_bf16"], err_fp32_mfma=errs["fp32"])
     assert errs["split_bf16"] <= 2.0 * errs["fp32"] + 2e-7, (case, errs)
+
+
+def _gru_seq_run(mode_fwd, mode_bwd, mod, x, h0, gout, agents, T):
+    """ops.gru on the persistent recurrences with SEQ_MODE = mode_fwd for the forward and mode_bwd for the backward launch"""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    old = ops.SEQ_MODE
+    try:
+        xs = x.clone().requires_grad_(True)
+        hs = h0.clone().requires_grad_(True)
+        mod.zero_grad()
+        ops.SEQ_MODE = mode_fwd
+        out, _ = ops.gru(xs, hs, mod, agents=agents, steps=T) if agents else ops.gru(xs, hs, mod)
+        ops.SEQ_MODE = mode_bwd
+        (out * gout).sum().backward()
+    finally:
+        ops.SEQ_MODE = old
+    return [out.detach().double(), xs.grad.double(), hs.grad.double()] + [p.grad.double().clone() for p in mod.parameters()]
+
+
+@pytest.mark.parametrize("T,n,P,agents,case", [(150, 26, 8, True, "randn"), (37, 5, 8, False, "randn"), (12, 3, 4, True, "randn"), (150, 26, 8, True, "cancel"),
+                                               (60, 9, 8, False, "wide")])
+def test_split_gru_sequence_matches_f64_beside_the_fp32_kernels(T, n, P, agents, case):
+    """The update's persistent GRU recurrences on the split-bf16 kernels (csrc/sb_gru_seq.hpp k_gru_seq_fwd_sb / k_gru_seq_bwd_sb) against
+    an f64 torch.nn.GRU, with the fp32-MFMA kernels (k_gru_seq_fwd2 / bwd2) beside them: outputs and every gradient (input, initial
+    state, W_ih, W_hh, both biases), two layers, the encoder's row order and the time-major one, sequence counts that leave a ragged last
+    tile; a recurrent weight whose products cancel and one with a wide dynamic range.  The saved gates of the two routes are
+    interchangeable: forward on one, backward on the other gives the same numbers."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(T + n)
+    B, E = n * P, 128
+    mod = torch.nn.GRU(E, E, 2).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    if case == "cancel":      # the second half of every recurrent dot product nearly cancels the first
+        with torch.no_grad():
+            for w in (mod.weight_hh_l0, mod.weight_hh_l1):
+                w[:, 64:] = -w[:, :64] + 1e-4 * torch.randn(384, 64, device="cuda", generator=gen)
+    if case == "wide":
+        with torch.no_grad():
+            for w in (mod.weight_hh_l0, mod.weight_hh_l1):
+                w.mul_(torch.exp2(torch.randint(-12, 3, w.shape, device="cuda", generator=gen).float()))
+    x = torch.randn(n * T * P, E, device="cuda", generator=gen) if agents else torch.randn(T, B, E, device="cuda", generator=gen)
+    h0 = torch.randn(2, B, E, device="cuda", generator=gen) * 0.5
+    if case == "cancel":
+        h0[:, :, 64:] = h0[:, :, :64]
+    gout = torch.randn(T, B, E, device="cuda", generator=gen)
+    m64 = torch.nn.GRU(E, E, 2).cuda().double()
+    m64.load_state_dict({k: v.double() for k, v in mod.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    h64 = h0.double().requires_grad_(True)
+    xin = x64.reshape(n, T, P, E).permute(1, 0, 2, 3).reshape(T, B, E) if agents else x64
+    o64, _ = m64(xin, h64)
+    (o64 * gout.double()).sum().backward()
+    ref = [o64.detach(), x64.grad, h64.grad] + [p.grad for p in m64.parameters()]
+    names = ["out", "dx", "dh0"] + [k for k, _ in mod.named_parameters()]
+    ag = P if agents else 0
+    res = {k: _gru_seq_run(a, b, mod, x, h0, gout, ag, T) for k, (a, b) in
+           dict(split=("split_bf16", "split_bf16"), fp32=("fp32", "fp32"), mixed1=("split_bf16", "fp32"), mixed2=("fp32", "split_bf16")).items()}
+    worst = {}
+    for k, r in res.items():
+        for nm, a, b in zip(names, r, ref):
+            scale = float(b.abs().max())
+            worst[(k, nm)] = float((a - b).abs().max()) / max(scale, 1e-30)
+    for nm in names:
+        e_s, e_f = worst[("split", nm)], worst[("fp32", nm)]
+        _record(test="gru_seq", case=case, T=T, B=B, agents=ag, tensor=nm, err_split=e_s, err_fp32_mfma=e_f)
+        assert e_s <= 2.0 * e_f + 2e-6, (nm, e_s, e_f)
+        assert e_s < 2e-5, (nm, e_s)
+        for k in ("mixed1", "mixed2"):
+            assert worst[(k, nm)] <= 2.0 * max(e_s, e_f) + 2e-6, (k, nm, worst[(k, nm)], e_s, e_f)
+    assert worst[("split", "out")] < 2e-6      # within 1e-6-ish of f64 like the fp32 kernels (test_gru_multi_* pin bit-identity of launch forms)

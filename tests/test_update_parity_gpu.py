@@ -42,9 +42,9 @@ def forced_kernels(monkeypatch):
         monkeypatch.setattr(L, name, counted)
     for n in ENTRY_POINTS:
         wrap(n)
-    modes = (ops.MATMUL_MODE, ops.WGRAD_MODE, ops.PROJ_MODE, ops.CELL_MODE)
+    modes = ops.matmul_modes()
     yield calls
-    ops.MATMUL_MODE, ops.WGRAD_MODE, ops.PROJ_MODE, ops.CELL_MODE = modes
+    ops.restore_matmul_modes(modes)
 
 
 def _expected_entry_points(E, mode):
@@ -154,7 +154,7 @@ def test_production_width_update_matches_the_f64_oracle(mode):
     from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
     GRAD_NOISE_FACTOR, GRAD_REL_FLOOR = 4.0, 2e-5
     N, MB = 64, 32
-    modes = (ops.MATMUL_MODE, ops.WGRAD_MODE, ops.PROJ_MODE, ops.CELL_MODE)
+    modes = ops.matmul_modes()
     try:
         cfg = baseline_config("cfg3", **{"runtime.num_envs": N, "runtime.seed": 11, "runtime.matmul": mode, "algo.sample_epi_num": 1})
         torch.manual_seed(5)
@@ -214,4 +214,4 @@ def test_production_width_update_matches_the_f64_oracle(mode):
             assert scale > 0, key
         print(f"[{mode}] worst gradient error / tolerance:", worst, "calls:", calls)
     finally:
-        ops.MATMUL_MODE, ops.WGRAD_MODE, ops.PROJ_MODE, ops.CELL_MODE = modes
+        ops.restore_matmul_modes(modes)
