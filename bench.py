@@ -162,22 +162,49 @@ def measure_compute_kernels(trainer, cfg):
         ptr = lambda t: C.c_void_p(t.data_ptr())
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         w, b = torch.randn(384, 128, device=dev) * 0.08, torch.zeros(384, device=dev)
-        t = timeit(lambda: L.gru_seq_fwd(T, B, 128, ptr(gi), ptr(w), ptr(b), ptr(h0[0]), ptr(o), None, 0, st))
-        out["gru_seq_fwd"] = entry("k_gru_seq_fwd2 (recurrent GEMM h W_hh^T + gates, T steps in one launch; no saved gates)", 2.0 * T * B * 128 * 384, t,
-                                   rows=B, steps=T)
+        seq_split = ops.SEQ_MODE == "split_bf16"
+        k_fwd, k_bwd = ("k_gru_seq_fwd_sb", "k_gru_seq_bwd_sb") if seq_split else ("k_gru_seq_fwd2", "k_gru_seq_bwd2")
+        f_fwd, f_bwd = (L.gru_seq_split_fwd_multi, L.gru_seq_split_bwd_multi) if seq_split else (L.gru_seq_fwd_multi, L.gru_seq_bwd_multi)
+        FWD_B, BWD_B = 4096.0, 5120.0     # HBM bytes per sequence row and step: gi + out + four saved gate planes | saved gates + h_prev + dout + dgi + dnr
+
+        def seq_records(Bs):
+            """forward / backward records of len(Bs) independent layers (one weight set: timing only)"""
+            keep, fa, ba = [], (ops.GruSeqNet * len(Bs))(), (ops.GruSeqBwdNet * len(Bs))()
+            for k_, b_ in enumerate(Bs):
+                ts = dict(gi=torch.randn(T, b_, 384, device=dev), h0=torch.zeros(b_, 128, device=dev), out=torch.empty(T, b_, 128, device=dev),
+                          save=torch.empty(L.gru_seq_save_elems(T, b_), device=dev), dout=torch.randn(T, b_, 128, device=dev),
+                          dgi=torch.empty(T, b_, 384, device=dev), dnr=torch.empty(T, b_, 128, device=dev), dh0=torch.empty(b_, 128, device=dev),
+                          dbi=torch.empty(384, device=dev), dbh=torch.empty(384, device=dev),
+                          ws=torch.empty(L.gru_seq_bwd_workspace(b_), dtype=torch.uint8, device=dev))
+                keep.append(ts)
+                a_ = fa[k_]
+                a_.gi, a_.w_hh, a_.b_hh, a_.h0, a_.out, a_.save, a_.B = (ts["gi"].data_ptr(), w.data_ptr(), b.data_ptr(), ts["h0"].data_ptr(), ts["out"].data_ptr(),
+                                                                          ts["save"].data_ptr(), b_)
+                a_ = ba[k_]
+                a_.dout, a_.save, a_.out, a_.h0, a_.w_hh, a_.dgi, a_.dgh, a_.dnr = (ts["dout"].data_ptr(), ts["save"].data_ptr(), ts["out"].data_ptr(), ts["h0"].data_ptr(),
+                                                                                    w.data_ptr(), ts["dgi"].data_ptr(), None, ts["dnr"].data_ptr())
+                a_.dh0, a_.db_ih, a_.db_hh, a_.workspace, a_.B = ts["dh0"].data_ptr(), ts["dbi"].data_ptr(), ts["dbh"].data_ptr(), ts["ws"].data_ptr(), b_
+            return keep, fa, ba
+
+        def seq_entry(kernel, t, rows, nbytes, **kw):
+            e = entry(kernel, 2.0 * T * rows * 128 * 384, t, split_kernel=seq_split, rows=rows, steps=T, **kw)
+            e.update(hbm_bytes_per_row_step=nbytes, hbm_GBps=round(nbytes * rows * T / t / 1e9, 1), frac_of_hbm=round(nbytes * rows * T / t / 1e9 / HBM_PEAK_GBS, 4))
+            return e
+        keep, fa, ba = seq_records([B])
+        t = timeit(lambda: f_fwd(1, C.cast(fa, C.c_void_p), T, B, 128, 0, st))
+        out["gru_seq_fwd"] = seq_entry(f"{k_fwd} (recurrent product h W_hh^T + gates of one layer of one mini-batch, T steps in one launch)", t, B, FWD_B)
+        del keep
         # the form the update launches (MAPPO._train_grouped): this layer of every mini-batch of the epoch and both networks at once
         N_envs = trainer.num_envs
         Bs = [(min(n0 + mb, N_envs) - n0) * P for n0 in range(0, N_envs, mb) for _ in range(2)]
         if 2 <= len(Bs) <= ops.GRU_MULTI_MAX_NETS:
-            gis = [torch.randn(T, b_, 384, device=dev) for b_ in Bs]
-            os_ = [torch.empty(T, b_, 128, device=dev) for b_ in Bs]
-            arr = (ops.GruSeqNet * len(Bs))()
-            for a_, g_, o_, b_ in zip(arr, gis, os_, Bs):
-                a_.gi, a_.w_hh, a_.b_hh, a_.h0, a_.out, a_.save, a_.B = g_.data_ptr(), w.data_ptr(), b.data_ptr(), h0.data_ptr(), o_.data_ptr(), None, b_
-            t = timeit(lambda: L.gru_seq_fwd_multi(len(Bs), C.cast(arr, C.c_void_p), T, max(Bs), 128, 0, st))
-            out["gru_seq_fwd_grouped"] = entry(f"k_gru_seq_fwd2, {len(Bs)} layers (every mini-batch of the epoch x actor, critic) in one launch: "
-                                               f"{sum((b_ + 15) // 16 for b_ in Bs)} workgroups", 2.0 * T * sum(Bs) * 128 * 384, t, rows=sum(Bs), steps=T)
-            del gis, os_
+            keep, fa, ba = seq_records(Bs)
+            wgs = sum((b_ + 15) // 16 for b_ in Bs)
+            t = timeit(lambda: f_fwd(len(Bs), C.cast(fa, C.c_void_p), T, max(Bs), 128, 0, st))
+            out["gru_seq_fwd_grouped"] = seq_entry(f"{k_fwd}, {len(Bs)} layers (every mini-batch of the epoch x actor, critic) in one launch: {wgs} workgroups", t, sum(Bs), FWD_B)
+            t = timeit(lambda: f_bwd(len(Bs), C.cast(ba, C.c_void_p), T, max(Bs), 128, 0, st))
+            out["gru_seq_bwd_grouped"] = seq_entry(f"{k_bwd}, the same {len(Bs)} layers backward in one launch (the largest single launch of an iteration)", t, sum(Bs), BWD_B)
+            del keep
         Kr = mb * T * P  # rows of one mini-batch: the weight gradient of a GRU projection reduces over all of them
         ga = torch.randn(Kr, 384, device=dev); xa = torch.randn(Kr, 128, device=dev)
         t = timeit(lambda: ops.wgrad(ga, xa))
@@ -222,7 +249,7 @@ def measure_compute_kernels(trainer, cfg):
     oo = torch.empty(R, P, E, device=dev)
     t = timeit(lambda: L.dhgn_msg_agg_ones_sorted_fwd(R, P, O, E, ptr(p), p.stride(0), ptr(q), q.stride(0), T, ptr(Ws[2]), ptr(bs[2]), ptr(oo), E, None, None, st))
     out["msg_agg_ones_sorted_fwd_critic"] = hbm_entry("k_msg_ones_sorted_fwd: the update's critic obstacle relation (all-ones adjacency): per-episode sort + prefix "
-                                                      "sums + binary search, O(log K) per pair", 4.0 * (p.numel() + q.numel()) + 4.0 * R * P * E, t, rows=R)
+                                                      "sums + a two-level rank search (16 register splitters, one 16-key bucket), O(log K) per pair", 4.0 * (p.numel() + q.numel()) + 4.0 * R * P * E, t, rows=R)
     return out
 
 
@@ -397,7 +424,8 @@ def run_config(name, args, with_roofline):
                workload=f"{name}: pursuit_evasion_game {P} defenders, {W}x{H} map, {N} envs/GPU, T={T}, DHGN depth {cfg.algo.depth} + "
                         f"2-layer GRU actor/critic, rollout + PPO update",
                envs_per_gpu=N, episode_steps=T, mini_batch_size=tr.mini_batch_size, backend=(dist.get_backend() if world > 1 else None),
-               update_group=tr.agent.update_group, hbm_peak_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1), matmul=_matmul_mode())
+               update_group=tr.agent.update_group, hbm_peak_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1), matmul=_matmul_mode(),
+               epochs=int(cfg.algo.epochs))
     # GEMM-shaped algorithmic work of one iteration (SURVEY 8d F_net without the message terms, which the kernels do not execute as
     # flops): per network and env-step; the rollout runs each network forward once, every epoch of the update forward + backward (3x)
     E_, H_, A_, d_ = cfg.algo.embedding_dim, cfg.algo.rnn_hidden_dim, cfg.env.action_dim, cfg.algo.depth
@@ -408,7 +436,10 @@ def run_config(name, args, with_roofline):
                                  "backward) over the measured iteration time, against the fp32 MFMA peak (the price of the fp32 formulation; with runtime.matmul: split_bf16 part of "
                                  "the products runs on the bf16 pipe at up to 2.67 x that rate)", "flops_per_net_env_step": f_net, "flops_per_iteration": flops_iter,
                                  "achieved": round(flops_iter / (dt / args.steps) / 1e12, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
-                                 "frac": round(flops_iter / (dt / args.steps) / 1e12 / FP32_PEAK_TF, 4)}
+                                 "frac": round(flops_iter / (dt / args.steps) / 1e12 / FP32_PEAK_TF, 4),
+                                 # the same flops against the pipe the default mode runs them on: six bf16 MFMAs per fp32 product, 2 500 / 6 TFLOP/s
+                                 "split_pipe_peak": round(2500.0 / 6.0, 1),
+                                 "frac_of_split_pipe": round(flops_iter / (dt / args.steps) / 1e12 / (2500.0 / 6.0), 4)}
     if with_roofline:
         tk = measure_env_tick(tr, args.tick_samples)
         tk_f32 = measure_env_tick(tr, args.tick_samples, packed=False)
@@ -527,6 +558,11 @@ def main():
             "roofline_iteration": main_res["roofline_iteration"], "roofline_replan_tick": main_res["roofline_replan_tick"],
             "roofline_compute_kernels": main_res.get("roofline_compute_kernels", {}),
         }
+        dom = main_res.get("roofline_compute_kernels", {}).get("gru_seq_bwd_grouped")
+        if dom is not None:   # where the iteration's largest launch stands, without opening profiles/
+            out["dominant_kernel"] = {"kernel": dom["kernel"], "us_per_launch": dom["us_per_launch"], "launches_per_iteration": int(2 * main_res.get("epochs", 1)),
+                                      "bound": "hbm (5 120 B per sequence row and step) beside the matrix pipe", "frac_of_hbm": dom["frac_of_hbm"],
+                                      "frac_of_matrix_pipe": dom["frac"], "matrix_pipe_peak_TFLOPs": dom["peak"]}
         if second is not None:
             out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "hbm_peak_GB", "workload", "roofline_iteration")}}
         if fp32_run is not None:

@@ -555,7 +555,7 @@ __global__ void k_msg_agg_bwd_reduce(int nblk, int E, int din, const float *part
 // prefix tables of d and of q (sorted order), then evaluates every (step, pursuer) by an 8-step binary search: O(log K)
 // instead of O(K) per pair.  Backward: dL/dc = g m, so db = sum g m, dW[:, k] = sum g (m p_i[k] - Q_k[m]) with Q_k the
 // prefix sums of q_j[k] in sorted order; m and the Q tables are saved by the forward pass.
-constexpr int SO_FC = 16, SO_TPB = 256, SO_PL = SO_TPB / SO_FC, SO_MAXK = 255, SO_LD = 257;  // 16 features x 16 pair lanes
+constexpr int SO_FC = 16, SO_TPB = 256, SO_PL = SO_TPB / SO_FC, SO_MAXK = 255, SO_LD = 260;  // 16 features x 16 pair lanes; rows 16-byte aligned
 
 struct SortedArgs {
     int R, P, K, E, q_div;
@@ -581,23 +581,62 @@ __global__ __launch_bounds__(SO_TPB) void k_msg_ones_sorted_fwd(SortedArgs a, fl
     const float bias = a.b[f0 + f];
     for (int j = tid; j < K; j += SO_TPB) s_q[j] = ((const float4 *)(a.q + (size_t)n * a.q_rs))[j];
     __syncthreads();
-    for (int j = pl; j < 256; j += SO_PL) {
-        s_key[f][j] = j < K ? msg_dot4(w, s_q[j]) : __builtin_inff();
-        s_idx[f][j] = (uint8_t)j;
-    }
-    __syncthreads();
-    for (int k = 2; k <= 256; k <<= 1)
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int e = pl; e < 128; e += SO_PL) {
-                const int i = ((e & ~(jj - 1)) << 1) | (e & (jj - 1)), ixj = i | jj;
-                const float x = s_key[f][i], y = s_key[f][ixj];
-                if ((x > y) == ((i & k) == 0)) {
-                    s_key[f][i] = y; s_key[f][ixj] = x;
-                    const uint8_t t = s_idx[f][i]; s_idx[f][i] = s_idx[f][ixj]; s_idx[f][ixj] = t;
+    // Sort the 256 (padded) keys of each of the 16 features IN REGISTERS, one wave per feature at a time (four features per wave),
+    // four keys per lane (element e = 64 r + lane): the bitonic network's exchanges at distance >= 64 are register moves, the rest
+    // wave shuffles -- no LDS traffic and no workgroup barrier inside the sort (rounds 2-3 sorted in LDS: 36 passes of eight
+    // compare-exchanges per thread with a barrier each were most of the kernel's 830 us).  Ties are broken by the obstacle index,
+    // so the network is a total order and the result does not depend on the exchange pattern.
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int ff = 0; ff < SO_FC / 4; ff++) {
+            const int fx = wv * (SO_FC / 4) + ff;
+            const float *wr = a.W + (size_t)(f0 + fx) * 4;
+            const float wx[4] = {wr[0], wr[1], wr[2], wr[3]};
+            float key[4];
+            int idx[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = 64 * r + lane;
+                key[r] = j < K ? msg_dot4(wx, s_q[j]) : __builtin_inff();
+                idx[r] = j;
+            }
+#pragma unroll
+            for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    if (jj >= 64) {
+                        const int dr = jj >> 6;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (r & dr) continue;
+                            const bool up = ((64 * r) & k) == 0;
+                            const float x = key[r], y = key[r | dr];
+                            const int ix = idx[r], iy = idx[r | dr];
+                            const bool gt = x > y || (x == y && ix > iy);
+                            if (gt == up) { key[r] = y; key[r | dr] = x; idx[r] = iy; idx[r | dr] = ix; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float y = __shfl_xor(key[r], jj);
+                            const int iy = __shfl_xor(idx[r], jj);
+                            const bool up = ((64 * r + lane) & k) == 0, lower = (lane & jj) == 0;
+                            const bool lt = key[r] < y || (key[r] == y && idx[r] < iy);
+                            const bool keep = (up == lower) == lt;    // the lower slot of an ascending pair keeps the smaller element
+                            key[r] = keep ? key[r] : y;
+                            idx[r] = keep ? idx[r] : iy;
+                        }
+                    }
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                s_key[fx][64 * r + lane] = key[r];
+                s_idx[fx][64 * r + lane] = (uint8_t)idx[r];
+            }
         }
+    }
+    __syncthreads();
     // prefix tables: 16 lanes per feature, each sums a contiguous chunk, then offsets by the chunks before it; the prefix
     // sums of d stay in LDS, those of q_j[0..3] (sorted order) go to qtab for the backward pass: [n][E][4][K + 1]
     const int ch = (K + SO_PL - 1) / SO_PL, m0 = pl * ch, m1 = (m0 + ch < K) ? m0 + ch : K;
@@ -614,32 +653,76 @@ __global__ __launch_bounds__(SO_TPB) void k_msg_ones_sorted_fwd(SortedArgs a, fl
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < pl; c++)
             for (int k = 0; k < 5; k++) acc[k] += s_chunk[(f * SO_PL + c) * 5 + k];
-        float *qt = qtab ? qtab + ((size_t)n * a.E + f0 + f) * 4 * (K + 1) : nullptr;
+        // qtab [episode][feature block][4][K + 1][16 features]: the 16 feature lanes of a pair lane store 64 contiguous bytes
+        // (rounds 2-3 kept [feature][4][K + 1]: every lane's 4-byte store its own transaction, 37 M of them per mini-batch)
+        float *qt = qtab ? qtab + ((size_t)n * gridDim.y + blockIdx.y) * 4 * (K + 1) * SO_FC + f : nullptr;
+        const int QS = (K + 1) * SO_FC;
         if (pl == 0) {
             s_pre[f * KP] = 0.f;
-            if (qt) for (int k = 0; k < 4; k++) qt[k * (K + 1)] = 0.f;
+            if (qt) for (int k = 0; k < 4; k++) qt[k * QS] = 0.f;
         }
         for (int m = m0; m < m1; m++) {
             const float4 qv = s_q[s_idx[f][m]];
             acc[0] += s_key[f][m]; acc[1] += qv.x; acc[2] += qv.y; acc[3] += qv.z; acc[4] += qv.w;
             s_pre[f * KP + m + 1] = acc[0];
-            if (qt) { qt[m + 1] = acc[1]; qt[(K + 1) + m + 1] = acc[2]; qt[2 * (K + 1) + m + 1] = acc[3]; qt[3 * (K + 1) + m + 1] = acc[4]; }
+            if (qt) {
+                float *q1 = qt + (m + 1) * SO_FC;
+                q1[0] = acc[1]; q1[QS] = acc[2]; q1[2 * QS] = acc[3]; q1[3 * QS] = acc[4];
+            }
         }
     }
     __syncthreads();
+    // rank m = #{j : d_j < c} of a query in TWO steps instead of an 8-step binary search (eight dependent LDS round trips per pair: the
+    // kernel was latency bound, 830 us per mini-batch): the last key of every 16-key bucket sits in a register (a thread serves ONE
+    // feature), so the bucket is a count of 16 register compares; the bucket's 16 keys are four independent 16-byte reads and another
+    // count.  Three pairs are in flight per thread; the query rows come through registers one group ahead.
+    float spl[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) spl[k] = s_key[f][16 * k + 15];
     const float invK = 1.f / (float)K;
     const int pairs = a.q_div * P;
-    for (int pi = pl; pi < pairs; pi += SO_PL) {
-        const int t = pi / P, i = pi - t * P;
-        const size_t row = (size_t)n * a.q_div + t;
-        const float4 pv = *(const float4 *)(a.p + row * a.p_rs + i * 4);
-        const float c = bias + w[0] * pv.x + w[1] * pv.y + w[2] * pv.z + w[3] * pv.w;
-        int m = 0;
+    constexpr int U = 3;
+    const size_t row0 = (size_t)n * a.q_div;
+    uint8_t *sm = save_m ? save_m + (((size_t)n * gridDim.y + blockIdx.y) * pairs) * SO_FC + f : nullptr;   // [episode][feature block][pair][16]: 16 lanes = 16 bytes
+    float4 pv[U];
+    auto load_p = [&](int base) {
 #pragma unroll
-        for (int step = 128; step > 0; step >>= 1)
-            if (m + step <= K && s_key[f][m + step - 1] < c) m += step;   // m = #{j : d_j < c}
-        out[(row * P + i) * a.o_is + f0 + f] = ((float)m * c - s_pre[f * KP + m]) * invK;
-        if (save_m) save_m[(row * P + i) * a.E + f0 + f] = (uint8_t)m;
+        for (int u = 0; u < U; u++) {
+            const int pi = base + u * SO_PL;
+            const int t = pi / P, i = pi - t * P;
+            pv[u] = pi < pairs ? *(const float4 *)(a.p + (row0 + t) * a.p_rs + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_p(pl);
+    for (int base = pl; base < pairs; base += U * SO_PL) {
+        float c[U];
+        int bk[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            c[u] = bias + w[0] * pv[u].x + w[1] * pv[u].y + w[2] * pv[u].z + w[3] * pv[u].w;
+            int b = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) b += spl[k] < c[u] ? 1 : 0;
+            bk[u] = b < 15 ? b : 15;          // (b = 16 needs a finite 256th key: K <= 255 keeps the last one +inf)
+        }
+        float4 kq[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) kq[u][q4] = *(const float4 *)&s_key[f][16 * bk[u] + 4 * q4];
+        if (base + U * SO_PL < pairs) load_p(base + U * SO_PL);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int pi = base + u * SO_PL;
+            if (pi >= pairs) continue;
+            int m = 16 * bk[u];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+                m += (kq[u][q4].x < c[u] ? 1 : 0) + (kq[u][q4].y < c[u] ? 1 : 0) + (kq[u][q4].z < c[u] ? 1 : 0) + (kq[u][q4].w < c[u] ? 1 : 0);
+            const int t = pi / P, i = pi - t * P;
+            out[((row0 + t) * P + i) * a.o_is + f0 + f] = ((float)m * c[u] - s_pre[f * KP + m]) * invK;
+            if (sm) sm[(size_t)pi * SO_FC] = (uint8_t)m;
+        }
     }
 }
 
@@ -649,29 +732,46 @@ __global__ __launch_bounds__(SO_TPB) void k_msg_ones_sorted_bwd(SortedArgs a, co
     extern __shared__ __attribute__((aligned(16))) float so_smem[];
     const int tid = threadIdx.x, f = tid & (SO_FC - 1), pl = tid >> 4;
     const int n = blockIdx.x, f0 = blockIdx.y * SO_FC, K = a.K, P = a.P, KQ = 4 * (K + 1);
-    float *s_qtab = so_smem;                       // [FC][4][K + 1], the layout of qtab
+    float *s_qtab = so_smem;                       // [FC][4][K + 1]: qtab's (episode, feature block) slice [4][K + 1][FC], transposed on the way in
     float *s_red = so_smem + SO_FC * 4 * (K + 2);   // [PL][FC][5]
     {
-        const float *src = qtab + ((size_t)n * a.E + f0) * KQ;
-        for (int idx = tid; idx < SO_FC * KQ; idx += SO_TPB) s_qtab[idx] = src[idx];
+        const float4 *src = (const float4 *)(qtab + ((size_t)n * gridDim.y + blockIdx.y) * KQ * SO_FC);
+        for (int idx = tid; idx < SO_FC * KQ / 4; idx += SO_TPB) {   // 16-byte coalesced reads: four features of one (k, m) entry
+            const float4 v = src[idx];
+            const int km = idx >> 2, fq = (idx & 3) * 4;
+            s_qtab[(fq + 0) * KQ + km] = v.x; s_qtab[(fq + 1) * KQ + km] = v.y; s_qtab[(fq + 2) * KQ + km] = v.z; s_qtab[(fq + 3) * KQ + km] = v.w;
+        }
     }
     __syncthreads();
     const float *s_qt = s_qtab + f * KQ;
     const float invK = 1.f / (float)K;
     float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb = 0.f;
     const int pairs = a.q_div * P;
-    for (int pi = pl; pi < pairs; pi += SO_PL) {
-        const int t = pi / P, i = pi - t * P;
-        const size_t row = (size_t)n * a.q_div + t;
-        const float4 pv = *(const float4 *)(a.p + row * a.p_rs + i * 4);
-        const float g = gout[(row * P + i) * a.o_is + f0 + f] * invK;
-        const int m = save_m[(row * P + i) * a.E + f0 + f];
-        const float gm = g * (float)m;
-        gb += gm;
-        gw[0] += gm * pv.x - g * s_qt[m];
-        gw[1] += gm * pv.y - g * s_qt[(K + 1) + m];
-        gw[2] += gm * pv.z - g * s_qt[2 * (K + 1) + m];
-        gw[3] += gm * pv.w - g * s_qt[3 * (K + 1) + m];
+    const uint8_t *sm = save_m + (((size_t)n * gridDim.y + blockIdx.y) * pairs) * SO_FC + f;    // the forward kernel's layout
+    const size_t row0 = (size_t)n * a.q_div;
+    constexpr int U = 4;   // pairs in flight per thread (every load of a pair is independent of the others)
+    for (int base = pl; base < pairs; base += U * SO_PL) {
+        float4 pv[U];
+        float g[U];
+        int m[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int pi = base + u * SO_PL;
+            const int t = pi / P, i = pi - t * P;
+            const bool ok = pi < pairs;
+            pv[u] = ok ? *(const float4 *)(a.p + (row0 + t) * a.p_rs + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[u] = ok ? gout[((row0 + t) * P + i) * a.o_is + f0 + f] * invK : 0.f;
+            m[u] = ok ? sm[(size_t)pi * SO_FC] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {     // ascending pair order per thread, as before: the sums round identically
+            const float gm = g[u] * (float)m[u];
+            gb += gm;
+            gw[0] += gm * pv[u].x - g[u] * s_qt[m[u]];
+            gw[1] += gm * pv[u].y - g[u] * s_qt[(K + 1) + m[u]];
+            gw[2] += gm * pv[u].z - g[u] * s_qt[2 * (K + 1) + m[u]];
+            gw[3] += gm * pv[u].w - g[u] * s_qt[3 * (K + 1) + m[u]];
+        }
     }
     for (int k = 0; k < 4; k++) s_red[(pl * SO_FC + f) * 5 + k] = gw[k];
     s_red[(pl * SO_FC + f) * 5 + 4] = gb;

@@ -105,9 +105,10 @@ int dhgn_msg_agg_bwd(int32_t R, int32_t P, int32_t K, int32_t E, int32_t din, co
  * The same aggregate for adjacency == ones over a neighbour set shared by q_div consecutive rows (the critic's obstacle relation
  * in training: torch.ones_like(adj) over the padded obstacle slots, AttributeDataset :64-65, q = the episode's obstacles) in
  * O(log K) per (row, agent, feature) instead of O(K): per (q-row, feature) the K pre-activation offsets d_j = W q_j are sorted
- * once, sum_j relu(c - d_j) = m c - prefix_d[m] with m = #{d_j < c} found by binary search (csrc/mappo_ops.hip
+ * once, sum_j relu(c - d_j) = m c - prefix_d[m] with m = #{d_j < c} found by a two-level rank search (csrc/mappo_ops.hip
  * k_msg_ones_sorted_*).  din == 4, K <= 255, E a multiple of 16, R a multiple of q_div (dhgn_msg_agg_ones_sorted_ok).
- * fwd: save_m [R][P][E] u8 and qtab [R/q_div][E][4][K+1] f32 (may be NULL without a backward pass) are what bwd consumes;
+ * fwd: save_m (R P E bytes) and qtab ((R / q_div) E 4 (K + 1) floats) -- both may be NULL without a backward pass -- are what bwd
+ * consumes; their layouts are private to the kernel pair ([q-row][block of 16 features][pair][16] and [q-row][block][4][K+1][16]);
  * bwd: dW [E][4], db [E] OVERWRITTEN; partials: scratch of the size dhgn_msg_agg_ones_sorted_workspace reports.
  * Sums are reassociated (prefix sums): results agree with dhgn_msg_agg_fwd/bwd(MO_ADJ_ONES) to fp32 rounding, not bit for bit.
  */

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "mappo_ops.h"
@@ -267,6 +268,28 @@ int main(int argc, char **argv) {
                 printf("    %-28s max |err| vs f64 on 97 rows: %.3g\n", what, worst);
             };
             const double bytes = (double)R * (K + N) * 4.0, flop = 2.0 * R * K * N;
+            // the OPT variants execute the same arithmetic in the same order: their results must be bit-identical
+            {
+                std::vector<float> y0(hy.size()), y1(hy.size());
+                for (int mode = 0; mode < 2; mode++) {        // plain (bias + ReLU), then in place Y += X W^T
+                    for (int variant = 0; variant < 4; variant++) {
+                        for (size_t q = 0; q < hy.size(); q++) hy[q] = (float)((q * 2654435761u) % 1000) * 1e-3f;
+                        CK(hipMemcpy(Y, hy.data(), hy.size() * 4, hipMemcpyHostToDevice));
+                        int rc = mode == 0 ? sbg_lab_launch(variant, R, N, K, X, K, W, K, B, nullptr, 0, Y, N, 1, 0)
+                                           : sbg_lab_launch(variant, R, N, K, X, K, W, K, nullptr, Y, N, Y, N, 0, 0);
+                        if (rc) continue;
+                        CK(hipDeviceSynchronize());
+                        CK(hipMemcpy((variant == 0 ? y0 : y1).data(), Y, hy.size() * 4, hipMemcpyDeviceToHost));
+                        if (variant > 0) {
+                            size_t bad = 0, first = 0;
+                            for (size_t q = 0; q < hy.size(); q++) if (memcmp(&y0[q], &y1[q], 4)) { if (!bad) first = q; bad++; }
+                            printf("N=%d K=%d rows=%lld %s OPT=%d vs OPT=0: %zu differing elements%s\n", N, K, (long long)R, mode ? "in place" : "plain", variant, bad,
+                                   bad ? " <-- HAZARD" : "");
+                            if (bad) printf("    first at row %zu col %zu: %.9g vs %.9g\n", first / N, first % N, y0[first], y1[first]);
+                        }
+                    }
+                }
+            }
             for (int variant = 0; variant < SBG_LAB_VARIANTS; variant++) {
                 CK(hipMemset(Y, 0, hy.size() * 4));
                 int rc = sbg_lab_launch(variant, R, N, K, X, K, W, K, B, nullptr, 0, Y, N, 1, 0);

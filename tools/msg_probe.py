@@ -70,3 +70,22 @@ with torch.no_grad():
     t_a = timeit(lambda: ops.msg_agg3(ob["p_state"], ob["e_state"], ob["o_state"], ob["p_adj"], ob["e_adj"], ob["o_adj_bits"], *wb, False, None, 1), 20)
     t_c = timeit(lambda: ops.msg_agg3(ob["p_state"], ob["e_state"], ob["o_state"], ob["p_adj"], ob["e_adj"], ob["o_adj_bits"], *wb, True, ob["o_kvalid"], 1), 20)
 print(f"rollout tick R={Rr}: pair {t_pair:.1f} us, actor {t_a:.1f} us, critic {t_c:.1f} us")
+
+# the critic's obstacle relation of the update through the sorted all-ones kernels (what MAPPO.train launches), C ABI directly
+import ctypes as C
+L = ops.load_library()
+ptr = lambda t: C.c_void_p(t.data_ptr())
+stc = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+W2, b2 = M[2].weight.detach().contiguous(), M[2].bias.detach().contiguous()
+K = o.shape[1]
+out_c = torch.empty(R, P, 3, E, device=p.device)
+save_m = torch.empty((R, P, E), dtype=torch.uint8, device=p.device)
+qtab = torch.empty((R // T, E, 4, K + 1), dtype=torch.float32, device=p.device)
+slot2 = C.c_void_p(out_c.data_ptr() + 4 * 2 * E)
+t_sf = timeit(lambda: L.dhgn_msg_agg_ones_sorted_fwd(R, P, K, E, ptr(p), p.stride(0), ptr(o), o.stride(0), T, ptr(W2), ptr(b2), slot2, 3 * E, ptr(save_m), ptr(qtab), stc))
+g3 = torch.randn(R, P, 3, E, device=p.device)
+dW, db = torch.empty_like(W2), torch.empty_like(b2)
+part = torch.empty((R // T) * 5 * E, dtype=torch.float32, device=p.device)
+gslot2 = C.c_void_p(g3.data_ptr() + 4 * 2 * E)
+t_sb = timeit(lambda: L.dhgn_msg_agg_ones_sorted_bwd(R, P, K, E, ptr(p), p.stride(0), T, gslot2, 3 * E, ptr(save_m), ptr(qtab), ptr(dW), ptr(db), ptr(part), stc))
+print(f"update obstacle  critic-sorted fwd {t_sf:8.1f} us  bwd {t_sb:8.1f} us   (k_msg_ones_sorted_fwd / bwd)")
