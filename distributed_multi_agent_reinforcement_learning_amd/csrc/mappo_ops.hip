@@ -174,24 +174,26 @@ template <int EV> __device__ __forceinline__ void msgw_weights(const MsgDims &d,
 }
 
 template <int PT, int EV>
-__device__ __forceinline__ void msgw_center(const MsgDims &d, const MsgRow &m, const FV<EV> (&w)[8], const FV<EV> &bias, FV<EV> (&c)[PT]) {
+// (i0: the first of the PT agents this wave serves -- a row's agents may be divided between waves, see launch_msgw3)
+__device__ __forceinline__ void msgw_center(const MsgDims &d, const MsgRow &m, const FV<EV> (&w)[8], const FV<EV> &bias, FV<EV> (&c)[PT], int i0 = 0) {
     const float e0 = rl_f(m.ve, 0), e1 = rl_f(m.ve, 1), e2 = rl_f(m.ve, 2), e3 = rl_f(m.ve, 3);
 #pragma unroll
     for (int i = 0; i < PT; i++) {
         c[i] = FV<EV>(0.f);
-        if (i < d.P) {
-            const float p0 = rl_f(m.vp, 4 * i), p1 = rl_f(m.vp, 4 * i + 1), p2 = rl_f(m.vp, 4 * i + 2), p3 = rl_f(m.vp, 4 * i + 3);
+        if (i0 + i < d.P) {
+            const int ia = i0 + i;
+            const float p0 = rl_f(m.vp, 4 * ia), p1 = rl_f(m.vp, 4 * ia + 1), p2 = rl_f(m.vp, 4 * ia + 2), p3 = rl_f(m.vp, 4 * ia + 3);
             c[i] = fv_fma(w[3], p3, fv_fma(w[2], p2, fv_fma(w[1], p1, fv_fma(w[0], p0, bias))));
             if (d.din == 8) c[i] = fv_fma(w[7], p3 - e3, fv_fma(w[6], p2 - e2, fv_fma(w[5], p1 - e1, fv_fma(w[4], p0 - e0, c[i]))));
         }
     }
 }
 
-// the actor's aggregate of one row: acc[i] = sum_j adj_ij relu(c_i - d_j), inv[i] = 1 / max(sum_j |adj_ij|, 1e-12)
+// the actor's aggregate of one row: acc[i] = sum_j adj_ij relu(c_i - d_j), inv[i] = 1 / max(sum_j |adj_ij|, 1e-12), for agents i0 .. i0 + PT - 1
 template <int PT, bool QS, bool AS, int EV>
 __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const MsgRow &m, const float4 *__restrict__ q4,
                                                const void *__restrict__ adj, const FV<EV> (&w)[8], const FV<EV> (&c)[PT], FV<EV> (&acc)[PT],
-                                               float (&inv)[PT]) {
+                                               float (&inv)[PT], int i0 = 0) {
     const int P = d.P, K = d.K;
     if (d.adj_mode == MO_ADJ_BITS) {
         const uint32_t *__restrict__ bw = (const uint32_t *)adj + (size_t)r * d.adj_rs;
@@ -200,10 +202,10 @@ __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const Ms
         for (int i = 0; i < PT; i++) {
             acc[i] = FV<EV>(0.f);
             inv[i] = 0.f;
-            if (i < P) {
+            if (i0 + i < P) {
                 int cnt = 0;
                 for (int wd = 0; wd < nw; wd++) {
-                    uint32_t bits = msgw_word<AS>(m, bw, i * RWK + wd);
+                    uint32_t bits = msgw_word<AS>(m, bw, (i0 + i) * RWK + wd);
                     if (wd == (K >> 5)) bits &= (1u << (K & 31)) - 1u;
                     cnt += __popc(bits);
                     while (bits) {
@@ -217,30 +219,35 @@ __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const Ms
         }
     } else if (AS) {  // MO_ADJ_TENSOR held in one register: the non-zero pattern as a 64-bit mask (bit i K + j)
         const MsgMask k = msgw_mask(m, P, K);
+        uint64_t col = 0ull;                   // bit i K of this wave's agents
 #pragma unroll
         for (int i = 0; i < PT; i++) {
             acc[i] = FV<EV>(0.f);
             inv[i] = 0.f;
-            if (i < P) inv[i] = 1.f / fmaxf(msgw_row_norm(m, k, i, K), 1e-12f);
+            if (i0 + i < P) {
+                inv[i] = 1.f / fmaxf(msgw_row_norm(m, k, i0 + i, K), 1e-12f);
+                col |= 1ull << ((i0 + i) * K);
+            }
         }
         for (int j = 0; j < K; j++) {
-            const uint64_t cm = (k.nz >> j) & k.col;  // bit i K: agent i sees neighbour j
+            const uint64_t cm = (k.nz >> j) & col;  // bit i K: agent i sees neighbour j
             if (cm == 0ull) continue;
             const FV<EV> dj = msg_dot4v(w, msgw_q<QS>(m, q4, j));
 #pragma unroll
             for (int i = 0; i < PT; i++)
-                if (i < P && ((cm >> (i * K)) & 1ull)) {
-                    const float aij = k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, i * K + j));
+                if (i0 + i < P && ((cm >> ((i0 + i) * K)) & 1ull)) {
+                    const float aij = k.zero_one ? 1.f : __uint_as_float(rl_u(m.va0, (i0 + i) * K + j));
                     acc[i] = fv_fma(fv_relu(c[i] - dj), aij, acc[i]);
                 }
         }
     } else {  // MO_ADJ_TENSOR read through uniform addresses
-        const float *__restrict__ ar = (const float *)adj + (size_t)r * d.adj_rs;
+        const float *__restrict__ ar = (const float *)adj + (size_t)r * d.adj_rs + (size_t)i0 * K;
+        const int pn = P - i0 < PT ? P - i0 : PT;      // this wave's agents
 #pragma unroll
         for (int i = 0; i < PT; i++) {
             acc[i] = FV<EV>(0.f);
             inv[i] = 0.f;
-            if (i < P) {
+            if (i < pn) {
                 float s = 0.f;
                 for (int j = 0; j < K; j++) s += fabsf(ar[i * K + j]);
                 inv[i] = 1.f / fmaxf(s, 1e-12f);
@@ -248,12 +255,12 @@ __device__ __forceinline__ void msgw_actor_row(const MsgDims &d, int r, const Ms
         }
         for (int j = 0; j < K; j++) {
             bool any = false;
-            for (int i = 0; i < P; i++) any |= ar[i * K + j] != 0.f;
+            for (int i = 0; i < pn; i++) any |= ar[i * K + j] != 0.f;
             if (!any) continue;
             const FV<EV> dj = msg_dot4v(w, msgw_q<QS>(m, q4, j));
 #pragma unroll
             for (int i = 0; i < PT; i++)
-                if (i < P) {
+                if (i < pn) {
                     const float aij = ar[i * K + j];
                     if (aij != 0.f) acc[i] = fv_fma(fv_relu(c[i] - dj), aij, acc[i]);
                 }
@@ -294,7 +301,7 @@ template <int PT, bool QS, bool AS, int EV>
 __device__ __forceinline__ void msgw_fwd_rows(const MsgDims &d, const float *__restrict__ p, const float *__restrict__ q,
                                               const float *__restrict__ e, const void *__restrict__ adj, const int32_t *__restrict__ kvalid,
                                               const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ out,
-                                              float *__restrict__ out_c, bool c_valid) {
+                                              float *__restrict__ out_c, bool c_valid, int i0 = 0) {
     const int P = d.P, f = threadIdx.x, fs = blockDim.x;
     FV<EV> w[8], bias;
     msgw_weights<EV>(d, W, b, f, w, bias, fs);
@@ -307,17 +314,17 @@ __device__ __forceinline__ void msgw_fwd_rows(const MsgDims &d, const float *__r
         const float4 *__restrict__ q4 = (const float4 *)(q + (size_t)(r / d.q_div) * d.q_rs);
         FV<EV> c[PT], acc[PT];
         float inv[PT];
-        msgw_center<PT, EV>(d, m, w, bias, c);
+        msgw_center<PT, EV>(d, m, w, bias, c, i0);
         if (out_c != nullptr) {
             FV<EV> acv[PT];
             msgw_ones_row<PT, QS, EV>(m.kv, m, q4, w, c, acv);
             const float inv_c = 1.f / fmaxf((float)m.kv, 1e-12f);
 #pragma unroll
             for (int i = 0; i < PT; i++)
-                if (i < P) fv_store<EV>(out_c + ((size_t)r * P + i) * d.o_is, f, fs, acv[i] * inv_c);
-            msgw_actor_row<PT, QS, AS, EV>(d, r, m, q4, adj, w, c, acc, inv);
+                if (i0 + i < P) fv_store<EV>(out_c + ((size_t)r * P + i0 + i) * d.o_is, f, fs, acv[i] * inv_c);
+            msgw_actor_row<PT, QS, AS, EV>(d, r, m, q4, adj, w, c, acc, inv, i0);
         } else if (d.adj_mode == MO_ADJ_TENSOR || d.adj_mode == MO_ADJ_BITS) {
-            msgw_actor_row<PT, QS, AS, EV>(d, r, m, q4, adj, w, c, acc, inv);
+            msgw_actor_row<PT, QS, AS, EV>(d, r, m, q4, adj, w, c, acc, inv, i0);
         } else {
             msgw_ones_row<PT, QS, EV>(m.kv, m, q4, w, c, acc);
             const float iv = 1.f / fmaxf((float)m.kv, 1e-12f);
@@ -326,7 +333,7 @@ __device__ __forceinline__ void msgw_fwd_rows(const MsgDims &d, const float *__r
         }
 #pragma unroll
         for (int i = 0; i < PT; i++)
-            if (i < P) fv_store<EV>(out + ((size_t)r * P + i) * d.o_is, f, fs, acc[i] * inv[i]);
+            if (i0 + i < P) fv_store<EV>(out + ((size_t)r * P + i0 + i) * d.o_is, f, fs, acc[i] * inv[i]);
         m = nxt;
     }
 }
@@ -351,10 +358,13 @@ __global__ __launch_bounds__(256) void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDi
                             const float *__restrict__ Wp, int64_t wp_rs, const float *__restrict__ bp, float *__restrict__ pos_a,
                             float *__restrict__ pos_c, int64_t pos_ld) {
     const int E = d0.E;
-    msgw_fwd_rows<PT, S01, S01, EV>(d0, p, q0, e0, adj0, kvalid2, W0, b0, out, out_c, false);
-    msgw_fwd_rows<PT, S01, S01, EV>(d1, p, q1, e0, adj1, kvalid2, W1, b1, out + E, out_c ? out_c + E : nullptr, false);
+    // blockIdx.y: which PT agents of the row this wave serves (launch_msgw3 divides a row between waves when there are few rows: a
+    // wave's work on a row is one long dependent stream -- 45 us per row at the rollout's shapes whatever the row count)
+    const int i0 = blockIdx.y * PT;
+    msgw_fwd_rows<PT, S01, S01, EV>(d0, p, q0, e0, adj0, kvalid2, W0, b0, out, out_c, false, i0);
+    msgw_fwd_rows<PT, S01, S01, EV>(d1, p, q1, e0, adj1, kvalid2, W1, b1, out + E, out_c ? out_c + E : nullptr, false, i0);
     // c_rel2 == 0 (the update): the critic's obstacle relation is left to the sorted all-ones kernel (k_msg_ones_sorted_fwd)
-    msgw_fwd_rows<PT, false, AS2, EV>(d2, p, q2, e0, adj2, kvalid2, W2, b2, out + 2 * E, (out_c && c_rel2) ? out_c + 2 * E : nullptr, c_valid != 0);
+    msgw_fwd_rows<PT, false, AS2, EV>(d2, p, q2, e0, adj2, kvalid2, W2, b2, out + 2 * E, (out_c && c_rel2) ? out_c + 2 * E : nullptr, c_valid != 0, i0);
     if (pos_a != nullptr) {
         // the position part of DHGN's semantic layer, bp + Wp p_i (Wp = the first four input columns, :284-303), for the same rows:
         // the addend the embedding part of that layer accumulates into; identical for actor and critic, written to both
@@ -369,11 +379,12 @@ __global__ __launch_bounds__(256) void k_msgw3_fwd(MsgDims d0, MsgDims d1, MsgDi
             const float vp = lane < 4 * P ? p[(size_t)r * d0.p_rs + lane] : 0.f;
 #pragma unroll
             for (int i = 0; i < PT; i++)
-                if (i < P) {
-                    const FV<EV> v = fv_fma(wp[3], rl_f(vp, 4 * i + 3), fv_fma(wp[2], rl_f(vp, 4 * i + 2), fv_fma(wp[1], rl_f(vp, 4 * i + 1),
-                                            fv_fma(wp[0], rl_f(vp, 4 * i), bias))));
-                    fv_store<EV>(pos_a + ((size_t)r * P + i) * pos_ld, f, fs, v);
-                    if (pos_c != nullptr) fv_store<EV>(pos_c + ((size_t)r * P + i) * pos_ld, f, fs, v);
+                if (i0 + i < P) {
+                    const int ia = i0 + i;
+                    const FV<EV> v = fv_fma(wp[3], rl_f(vp, 4 * ia + 3), fv_fma(wp[2], rl_f(vp, 4 * ia + 2), fv_fma(wp[1], rl_f(vp, 4 * ia + 1),
+                                            fv_fma(wp[0], rl_f(vp, 4 * ia), bias))));
+                    fv_store<EV>(pos_a + ((size_t)r * P + ia) * pos_ld, f, fs, v);
+                    if (pos_c != nullptr) fv_store<EV>(pos_c + ((size_t)r * P + ia) * pos_ld, f, fs, v);
                 }
         }
     }
@@ -2001,9 +2012,11 @@ struct SbWgCfg {
 
 // feature f's slot in the LDS image
 __device__ __forceinline__ int sb_swz(int f) { return (f & ~3) | ((f & 3) ^ ((f >> 3) & 3)); }
+// A may come in two column blocks (A2 != nullptr: columns M1 .. M - 1 from A2, row stride lda2): the GRU's dW_hh = [dr dz | dnr]^T h_prev
+// takes (dr, dz) from dgi and dnr from its own tensor in ONE pass over h_prev.
 template <int MT, int NT>
 __global__ __launch_bounds__(512) void k_sb_wgrad(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int64_t K,
-                                                  float *__restrict__ part) {
+                                                  float *__restrict__ part, const float *__restrict__ A2, int64_t lda2, int M1) {
     using C = SbWgCfg<MT, NT>;
     extern __shared__ uint4 sb_lds[];                    // [buffer][piece][octet][feature slot] x 16 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2012,8 +2025,9 @@ __global__ __launch_bounds__(512) void k_sb_wgrad(const float *__restrict__ A, i
     const bool on = tid < C::UNITS;
     const int rest = on ? tid / C::FQ : 0, col = 4 * (tid % C::FQ);
     const int row_in_chunk = 4 * rest;                   // = 8 octet + 4 half
-    const float *src = (col < C::M ? A + col : B + (col - C::M)) + row_in_chunk * (col < C::M ? lda : ldb);
-    const int64_t ld = col < C::M ? lda : ldb;
+    const bool in_a2 = A2 != nullptr && col >= M1 && col < C::M;
+    const int64_t ld = in_a2 ? lda2 : (col < C::M ? lda : ldb);
+    const float *src = (in_a2 ? A2 + (col - M1) : (col < C::M ? A + col : B + (col - C::M))) + row_in_chunk * ld;
     const int slot2 = 2 * ((rest >> 1) * C::COLS + col) + (rest & 1), sx = (col >> 3) & 3;   // in 8-byte units
     // multiplier role
     const int wm = wave / C::WGN, wn = wave % C::WGN;
@@ -2364,13 +2378,18 @@ int launch_msgw3(const mo_msg_rel *rel, int R, int P, int E, const float *p, int
     const bool s01 = msg_q_small(rel[0].K) && msg_q_small(rel[1].K) && msg_adj_small(P, rel[0].K, rel[0].adj_mode) &&
                      msg_adj_small(P, rel[1].K, rel[1].adj_mode);
     const bool as2 = msg_adj_small(P, rel[2].K, rel[2].adj_mode), ev2 = (E % 128) == 0;
+    // Few rows (the rollout's tick: one row per environment): a row's agents are divided between two waves (PT = 4 of 8, or 8 of 16) --
+    // twice the waves, half the dependent work per wave; the neighbour offsets d_j are then computed by both (+14 % arithmetic), which
+    // is why launches with more rows keep one wave per row (measured at 4 096 rows: 77 us whole, 83 us halved; at 512 rows: see DESIGN 6).
+    const bool halves = R <= 2048 && P > 4;
+    const int pt = halves ? (P <= 8 ? 4 : 8) : (P <= 8 ? 8 : 16), gy = (P + pt - 1) / pt;
 #define MSGW3_LAUNCH1(PT, S01, AS2, EV)                                                                                                     \
-    hipLaunchKernelGGL((k_msgw3_fwd<PT, S01, AS2, EV>), dim3(grid), dim3(E / EV), 0, (hipStream_t)stream, d[0], d[1], d[2], p, rel[0].q,       \
+    hipLaunchKernelGGL((k_msgw3_fwd<PT, S01, AS2, EV>), dim3(grid, gy), dim3(E / EV), 0, (hipStream_t)stream, d[0], d[1], d[2], p, rel[0].q,   \
                        rel[0].e, rel[0].adj, rel[0].W, rel[0].b, rel[1].q, rel[1].adj, rel[1].W, rel[1].b, rel[2].q, rel[2].adj, kvalid2,      \
                        rel[2].W, rel[2].b, out, out_c, c_valid, c_rel2, Wp, wp_rs, bp, pos_a, pos_c, pos_ld ? pos_ld : (int64_t)E)
 #define MSGW3_LAUNCH(PT, S01, AS2) do { if (ev2) MSGW3_LAUNCH1(PT, S01, AS2, 2); else MSGW3_LAUNCH1(PT, S01, AS2, 1); } while (0)
 #define MSGW3_PT(PT) { if (s01 && as2) MSGW3_LAUNCH(PT, true, true); else if (s01) MSGW3_LAUNCH(PT, true, false); else if (as2) MSGW3_LAUNCH(PT, false, true); else MSGW3_LAUNCH(PT, false, false); }
-    if (P <= 8) MSGW3_PT(8) else MSGW3_PT(16)
+    if (pt == 4) MSGW3_PT(4) else if (pt == 8) MSGW3_PT(8) else MSGW3_PT(16)
 #undef MSGW3_PT
 #undef MSGW3_LAUNCH
 #undef MSGW3_LAUNCH1
@@ -2386,14 +2405,15 @@ static bool sb_wgrad_shape_ok(int M, int N) {
 }
 
 template <int MT, int NT>
-int launch_sb_wgrad(int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *Cm, int accumulate, float *part, hipStream_t st) {
+int launch_sb_wgrad(int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *Cm, int accumulate, float *part, hipStream_t st,
+                    const float *A2 = nullptr, int64_t lda2 = 0, int M1 = 0) {
     using C = SbWgCfg<MT, NT>;
     static_assert(C::UNITS <= 512 && C::WGM * C::WGN == 8 && C::TM * C::WGM * 32 == C::M && C::TN * C::WGN * 32 == C::N && SB_DEPTH % 2 == 0, "tiling");
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [] { attr_rc = hipFuncSetAttribute((const void *)k_sb_wgrad<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); });
     if (attr_rc != hipSuccess) return (int)attr_rc;
-    hipLaunchKernelGGL((k_sb_wgrad<MT, NT>), dim3(SB_WGRAD_WGS), dim3(512), C::LDS_BYTES, st, A, lda, B, ldb, K, part);
+    hipLaunchKernelGGL((k_sb_wgrad<MT, NT>), dim3(SB_WGRAD_WGS), dim3(512), C::LDS_BYTES, st, A, lda, B, ldb, K, part, A2, lda2, M1);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((C::M * C::N + 63) / 64), dim3(256), 0, st, SB_WGRAD_WGS, C::M * C::N, (const float *)part, Cm, accumulate);
     return (int)hipGetLastError();
 }
@@ -2785,6 +2805,20 @@ int wgrad_split_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda,
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
 #define SB_WG(mt, nt) if (M == 128 * mt && N == 128 * nt) return launch_sb_wgrad<mt, nt>(K, A, lda, B, ldb, C, accumulate, part, st);
+    SB_WG(1, 1) SB_WG(1, 2) SB_WG(2, 1) SB_WG(1, 3) SB_WG(3, 1)
+#undef SB_WG
+    return MO_ERR_BAD_ARG;
+}
+
+int wgrad_split_tn2(int64_t K, int32_t M1, int32_t M2, int32_t N, const float *A1, int64_t lda1, const float *A2, int64_t lda2, const float *B, int64_t ldb,
+                    float *C, int32_t accumulate, void *workspace, void *stream) {
+    const int M = M1 + M2;
+    if (K < 1 || M1 < 4 || M2 < 4 || (M1 & 3) || (M2 & 3) || !sb_wgrad_shape_ok(M, N) || !A1 || !A2 || !B || !C || !workspace) return MO_ERR_BAD_ARG;
+    if (lda1 < M1 || lda2 < M2 || ldb < N || (lda1 & 3) || (lda2 & 3) || (ldb & 3) || ((uintptr_t)A1 & 15) || ((uintptr_t)A2 & 15) || ((uintptr_t)B & 15))
+        return MO_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+#define SB_WG(mt, nt) if (M == 128 * mt && N == 128 * nt) return launch_sb_wgrad<mt, nt>(K, A1, lda1, B, ldb, C, accumulate, part, st, A2, lda2, M1);
     SB_WG(1, 1) SB_WG(1, 2) SB_WG(2, 1) SB_WG(1, 3) SB_WG(3, 1)
 #undef SB_WG
     return MO_ERR_BAD_ARG;

@@ -15,7 +15,7 @@ ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "gae_advnorm_workspace", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "sb_gemm", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_split_fwd_multi", "gru_seq_split_bwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "wgrad_split_tn", "wgrad_split_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "sb_gemm", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_split_fwd_multi", "gru_seq_split_bwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "wgrad_split_tn", "wgrad_split_tn2", "wgrad_split_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -78,6 +78,7 @@ def load_library():
         L.wgrad_split_workspace.restype = i64
         L.wgrad_split_workspace.argtypes = [i32, i32]
         L.wgrad_split_tn.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp]
+        L.wgrad_split_tn2.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, vp, vp]
         L.fcra_neighbour_mean.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, vp, vp, i64, vp]
         L.fcra_neighbour_mean_multi.argtypes = [i32, vp, i32, i32, i32, i32, i64, i64, i64, i64, vp, i64, i32, i64, vp]
         L.relu_bwd_colsum_workspace.argtypes = [i32]
@@ -1419,8 +1420,16 @@ def _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H):
     torch.mm(drz[:B].t(), h0, out=dw_hh[:2 * H])
     torch.mm(dnr[0].t(), h0, out=dw_hh[2 * H:])
     if T > 1:
-        wgrad(drz[B:], hp, out=dw_hh[:2 * H], accumulate=True)
-        wgrad(dnr[1:].reshape((T - 1) * B, H), hp, out=dw_hh[2 * H:], accumulate=True)
+        a1, a2 = drz[B:], dnr[1:].reshape((T - 1) * B, H)
+        if WGRAD_MODE == "split_bf16" and H == 128 and _wgrad_ok(a1, hp) and _wgrad_ok(a2, hp):
+            # [dr dz | dnr]^T h_prev in ONE pass over h_prev (k_sb_wgrad with its left operand in two tensors)
+            L = load_library()
+            ws = torch.empty(L.wgrad_split_workspace(3 * H, H), dtype=torch.uint8, device=dgi.device)
+            _check(L.wgrad_split_tn2(a1.shape[0], 2 * H, H, H, _ptr(a1), a1.stride(0), _ptr(a2), a2.stride(0), _ptr(hp), hp.stride(0), _ptr(dw_hh), 1,
+                                     _ptr(ws), _stream()), "wgrad_split_tn2")
+        else:
+            wgrad(a1, hp, out=dw_hh[:2 * H], accumulate=True)
+            wgrad(a2, hp, out=dw_hh[2 * H:], accumulate=True)
     return dw_hh
 
 

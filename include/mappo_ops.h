@@ -305,6 +305,10 @@ int wgrad_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const
 int64_t wgrad_split_workspace(int32_t M, int32_t N);
 int wgrad_split_tn(int64_t K, int32_t M, int32_t N, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int32_t accumulate,
                    void *workspace, void *stream);
+/* The same with A given as two column blocks [A1 (K x M1) | A2 (K x M2)], M = M1 + M2 (each with its own row stride): one pass over B for
+ * a product whose left operand lives in two tensors -- the GRU's dW_hh = [dr dz | dnr]^T h_prev (dr, dz: the first 2H columns of dgi). */
+int wgrad_split_tn2(int64_t K, int32_t M1, int32_t M2, int32_t N, const float *A1, int64_t lda1, const float *A2, int64_t lda2, const float *B, int64_t ldb,
+                    float *C, int32_t accumulate, void *workspace, void *stream);
 /*
  * Neighbour mean of DHGN.fcra (DHGN/mappo_parallel.py:204-233: `torch.matmul(F.normalize(adj, p=1, dim=-1), hist)`), R rows of P
  * agents and E features:  out[r][i][:] = act( sum_j abar[r][i][j] z[r][j][:] + bias ),  act = ReLU when relu != 0.

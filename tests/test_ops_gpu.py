@@ -951,3 +951,47 @@ def test_fcra_hop_forward_and_backward_match_f64(mode):
     for a, b in zip(params + [h0g], p64 + [h64]):
         scale = float(b.grad.abs().max())
         assert float((a.grad.double() - b.grad).abs().max()) <= 3e-5 * scale + 1e-7, (a.shape, scale)
+
+
+def test_split_wgrad_with_the_left_operand_in_two_tensors():
+    """wgrad_split_tn2: [A1 | A2]^T B with A1 a column slice of a wider matrix (dgi's first 2H columns) and A2 its own tensor (dnr) -- the
+    GRU's dW_hh in one pass over h_prev -- equals the two separate products (same split arithmetic, same split-K partials) and f64."""
+    import ctypes as C
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(11)
+    K, H = 61237, 128
+    dgi = torch.randn(K, 3 * H, device="cuda") * 0.1
+    dnr = torch.randn(K, H, device="cuda") * 0.1
+    hp = torch.randn(K, H, device="cuda")
+    a1 = dgi[:, :2 * H]
+    L = ops.load_library()
+    out = torch.full((3 * H, H), 7.0, device="cuda")
+    base = out.clone()
+    ws = torch.empty(L.wgrad_split_workspace(3 * H, H), dtype=torch.uint8, device="cuda")
+    ops._check(L.wgrad_split_tn2(K, 2 * H, H, H, ops._ptr(a1), a1.stride(0), ops._ptr(dnr), dnr.stride(0), ops._ptr(hp), hp.stride(0), ops._ptr(out), 1,
+                                 ops._ptr(ws), ops._stream()), "wgrad_split_tn2")
+    ref = torch.cat((a1, dnr), 1).double().t() @ hp.double()
+    err = float((out.double() - base.double() - ref).abs().max() / ref.abs().max())
+    old = ops.WGRAD_MODE
+    ops.WGRAD_MODE = "split_bf16"
+    try:
+        two = torch.cat((ops.wgrad(a1, hp), ops.wgrad(dnr, hp)), 0)
+    finally:
+        ops.WGRAD_MODE = old
+    assert err < 3e-6, err
+    assert float((out - base - two).abs().max()) <= 1e-5 * float(two.abs().max())      # (accumulate adds into 7.0: one more rounding)
+    # the product's route: ops._gru_dw_hh takes it for time-major gradients
+    T, B = 40, 200
+    dgi3, dnr3, out3, h0 = torch.randn(T * B, 3 * H, device="cuda"), torch.randn(T, B, H, device="cuda"), torch.randn(T, B, H, device="cuda"), torch.randn(B, H, device="cuda")
+    calls = []
+    real = L.wgrad_split_tn2
+    L.wgrad_split_tn2 = lambda *a: (calls.append(1), real(*a))[1]
+    try:
+        ops.WGRAD_MODE = "split_bf16"
+        dw = ops._gru_dw_hh(dgi3, None, dnr3, out3, h0, T, B, H)
+    finally:
+        L.wgrad_split_tn2 = real
+        ops.WGRAD_MODE = old
+    hprev = torch.cat((h0[None], out3[:-1]), 0).reshape(T * B, H).double()
+    want = torch.cat((dgi3[:, :2 * H], dnr3.reshape(T * B, H)), 1).double().t() @ hprev
+    assert calls and float((dw.double() - want).abs().max() / want.abs().max()) < 3e-6
