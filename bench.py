@@ -28,8 +28,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TF = 157.3    # fp32 vector == fp32 MFMA peak
-PMC_FILES = {"packed": [os.path.join(ROOT, "profiles", n) for n in ("r03_tick_pmc.json", "r02_tick_pmc.json")],   # newest first
-             "fp32": [os.path.join(ROOT, "profiles", "r03_tick_pmc_fp32.json")]}
+PMC_FILES = {"packed": [os.path.join(ROOT, "profiles", n) for n in ("r04_tick_pmc.json", "r03_tick_pmc.json", "r02_tick_pmc.json")],   # newest first
+             "fp32": [os.path.join(ROOT, "profiles", n) for n in ("r04_tick_pmc_fp32.json", "r03_tick_pmc_fp32.json")]}
 
 
 def algorithmic_bytes_per_env_step(P, W, H, O):

@@ -294,6 +294,10 @@ class BatchedEnv:
         if self._pending:
             torch.cuda.current_stream().wait_event(self._ev_evader)
             self._pending = False
+        ev = self.__dict__.get("_ev_reset")
+        if ev is not None:      # a device reset issued ahead on the side stream (Pursuit_Env.prefetch_reset)
+            torch.cuda.current_stream().wait_event(ev)
+            self.__dict__["_ev_reset"] = None
 
     def observe(self, obs=None):
         self._join()
@@ -420,11 +424,17 @@ class DeviceResetter:
             _check(self.L.pe_env_reset_seed(C.byref(self.c), self.N, _np(s), _ptr(self.state), _stream()), "pe_env_reset_seed")
         self.first = True
 
-    def get_state(self):
-        d = dict(blob=self.state.cpu().numpy(), first=self.first, device=True)
+    def get_state(self, snapshot=None):
+        """the resume-bundle form (host arrays); snapshot: a snapshot_device() result to convert instead of the live state"""
+        src = snapshot if snapshot is not None else dict(blob=self.state, first=self.first, bank_rng=self.bank_rng.getstate() if self.bank is not None else None)
+        d = dict(blob=src["blob"].cpu().numpy(), first=src["first"], device=True)
         if self.bank is not None:
-            d["bank_rng"] = self.bank_rng.getstate()
+            d["bank_rng"] = src["bank_rng"]
         return d
+
+    def snapshot_device(self):
+        """the generator streams as they stand, kept on the device (no host copy, no synchronisation)"""
+        return dict(blob=self.state.clone(), first=self.first, bank_rng=self.bank_rng.getstate() if self.bank is not None else None)
 
     def set_state(self, state):
         buf = np.ascontiguousarray(state["blob"], np.uint8)
@@ -438,6 +448,12 @@ class DeviceResetter:
     def reset(self, reset_reward_norm=False):
         """Next episode of every environment, in place in the simulator state (reads the finished episode's tape position
         from the device)."""
+        self.launch(reset_reward_norm)
+        self.check()
+
+    def launch(self, reset_reward_norm=False):
+        """the reset kernels on the current stream, no read-back (Pursuit_Env.prefetch_reset issues them on a side stream under the
+        PPO update; check() follows when the episode starts)"""
         sim = self.sim
         sim._join()
         if self.bank is not None:
@@ -448,6 +464,9 @@ class DeviceResetter:
                                        _ptr(sim.o_state), 1 if reset_reward_norm else 0, _stream()), "pe_env_reset")
         self.first = False
         sim.t_host = 0
+
+    def check(self):
+        sim = self.sim
         # one blocking read-back per episode: the largest obstacle count and the sticky kernel status bits (pe_env.h: the
         # finished episode's tape-exhausted / A*-cap / path-underflow bits are carried into the new meta record by the reset)
         worst, bits = torch.stack((sim.n_obs.max(), status_or(sim.meta))).tolist()

@@ -52,9 +52,17 @@ class Pursuit_Env:
         self.time_step = 0
         self.n_episode += 1
         if init is None and self.device_reset:
-            self.resetter.reset()
+            ev = getattr(self, "_dev_prefetch", None)
+            if ev is not None:          # the reset kernels already ran on the side stream (prefetch_reset): order this stream behind them
+                torch.cuda.current_stream().wait_event(ev)
+                self._dev_prefetch = self._pre_reset = None
+                self.resetter.check()
+            else:
+                self.resetter.reset()
             self.last_init = None
             return None
+        if init is not None and getattr(self, "_dev_prefetch", None) is not None:
+            raise RuntimeError("an injected initial condition after prefetch_reset(): the device reset of the next episode has already run")
         if init is None:
             init = self._take_prefetched()
             if init is None:
@@ -69,7 +77,23 @@ class Pursuit_Env:
         """Starts the host-side reset of the next episode in a background thread (the C++ resetter releases the GIL).  Call
         it once the running episode is over: the number of tape targets it consumed is read here."""
         import threading
-        if self.device_reset or getattr(self, "_prefetch", None) is not None:
+        if self.device_reset:
+            # device reset: the next episode's reset kernels (k_reset, k_build_bidx, k_build_raser: ~4 ms at 4096 environments, VALU
+            # work) run on the simulator's side stream under whatever the caller launches next -- the HBM-bound PPO update, which
+            # reads the replay buffer only, never the simulator state.  reset() then waits for the event instead of launching.
+            if getattr(self, "_dev_prefetch", None) is None:
+                # what a resume bundle written from now on must hold (trainer.Trainer.save_resume): the state the reset starts from
+                self._pre_reset = dict(resetter=self.resetter.snapshot_device(), tape_pos=self.sim.meta[:, pe_env.META_TAPE_POS].clone())
+                side = self.sim._side
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self.resetter.launch()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                self._dev_prefetch = ev
+                self.sim._ev_reset = ev      # any reader of the simulator state on another stream waits for it (BatchedEnv._join)
+            return
+        if getattr(self, "_prefetch", None) is not None:
             return
         self.check_status()
         consumed = None if self.resetter.first else self.sim.meta[:, pe_env.META_TAPE_POS].cpu().numpy()

@@ -168,7 +168,7 @@ class Trainer:
         ev[0].record()
         exp_r, buffer, steps = agent.explore_env(self.env, int(cfg.algo.sample_epi_num))
         ev[1].record()
-        self.env.prefetch_reset()  # the host builds the next episode's maps while the GPU runs the update
+        self.env.prefetch_reset()  # the next episode's reset (device: kernels on the side stream; host: a thread) runs while the GPU runs the update
         self.total_steps += steps * self.world
         for _ in range(int(cfg.algo.epochs)):
             with torch.enable_grad():
@@ -187,11 +187,15 @@ class Trainer:
     def save_resume(self, path):
         env, agent = self.env, self.agent
         init = env._take_prefetched()  # the next episode may already be drawn: it belongs to the snapshot
+        # ... or already reset on the device (prefetch_reset): the bundle then carries the generator streams and tape positions as they
+        # stood BEFORE that reset, so the resumed run's first reset re-creates the same episode
+        pre = getattr(env, "_pre_reset", None) if getattr(env, "_dev_prefetch", None) is not None else None
         st = getattr(agent, "_rstate", None)
         bundle = dict(actor=agent.actor.state_dict(), critic=agent.critic.state_dict(), optimizer=agent.ac_optimizer.state_dict(),
                       total_steps=self.total_steps, iteration=self.iteration, reward_norm=env.sim.rn.cpu(),
-                      tape_pos=env.sim.meta[:, 2].cpu(), sample_counter=None if st is None else st.counter.cpu(),
-                      resetter=env.resetter.get_state(), next_init=init, num_envs=self.num_envs, world=self.world, rank=self.rank)
+                      tape_pos=(env.sim.meta[:, 2] if pre is None else pre["tape_pos"]).cpu(), sample_counter=None if st is None else st.counter.cpu(),
+                      resetter=env.resetter.get_state() if pre is None else env.resetter.get_state(pre["resetter"]), next_init=init,
+                      num_envs=self.num_envs, world=self.world, rank=self.rank)
         torch.save(bundle, path)
         if init is not None:
             env._prefetch = (_Done(), {"init": init})
@@ -201,6 +205,9 @@ class Trainer:
         if b["num_envs"] != self.num_envs or b["world"] != self.world:
             raise ValueError("resume bundle was written for another num_envs / world size")
         env, agent = self.env, self.agent
+        if getattr(env, "_dev_prefetch", None) is not None:    # a device reset issued ahead belongs to the run being replaced: let it finish, drop it
+            torch.cuda.current_stream().wait_stream(env.sim._side)
+            env._dev_prefetch = env._pre_reset = None
         agent.actor.load_state_dict(b["actor"]); agent.critic.load_state_dict(b["critic"])
         agent.ac_optimizer.load_state_dict(b["optimizer"])
         self.total_steps, self.iteration = b["total_steps"], b["iteration"]

@@ -1,4 +1,4 @@
-"""rocprofv3 outputs of tools/profile_gru.py -> profiles/r03_gru_mfma_counters.json: per hand-written MFMA kernel the average
+"""rocprofv3 outputs of tools/profile_gru.py -> profiles/r04_gru_mfma_counters.json: per hand-written MFMA kernel the average
 duration (kernel trace), MFMA busy cycles, and MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE x #SIMDs) -- the
 derived-counter formula rocprofv3 lists for MfmaUtil -- next to the algorithmic fp32 rate against the 157.3 TFLOP/s peak.
   python tools/mfma_summary.py <dir>"""
@@ -7,11 +7,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
 GROUPED = "--grouped" in sys.argv    # <dir> holds the passes of `tools/profile_gru.py --grouped`: 18 x 3280 + 2 x 3248 sequences per launch
 ROWS = 18 * 3280 + 2 * 3248 if GROUPED else 3280
-KERNELS = {"k_gru_seq_fwd2": 2.0 * 150 * ROWS * 128 * 384, "k_gru_seq_bwd2": 2.0 * 150 * ROWS * 384 * 128}
-if not GROUPED:   # substring -> algorithmic fp32 flops per launch ("k_gru_cell(" so that it does not match k_gru_cell_sb)
+KERNELS = {"k_gru_seq_fwd2": 2.0 * 150 * ROWS * 128 * 384, "k_gru_seq_bwd2": 2.0 * 150 * ROWS * 384 * 128,
+           "k_gru_seq_fwd_sb": 2.0 * 150 * ROWS * 128 * 384, "k_gru_seq_bwd_sb": 2.0 * 150 * ROWS * 384 * 128}
+if GROUPED:
+    KERNELS["k_sb_gemm_n128<12, 1,"] = 2.0 * 492000 * 384 * 128       # the update's 384-input product at mini-batch size
+else:   # substring -> algorithmic fp32 flops per launch ("k_gru_cell(" so that it does not match k_gru_cell_sb)
     KERNELS.update({"k_gru_cell(": 2.0 * 32768 * 128 * 768, "k_gru_cell_sb": 2 * 2.0 * 32768 * 128 * 768, "k_wgrad<3, 1>": 2.0 * 492000 * 384 * 128,
-                    "k_sb_wgrad<3, 1>": 2.0 * 492000 * 384 * 128, "k_sb_gemm_n128<4, 1>": 2.0 * 196608 * 128 * 128,
-                    "k_sb_gemm_n128<12, 1>": 2.0 * 65536 * 384 * 128, "k_sb_gemm_n128<4, 3>": 2.0 * 492000 * 128 * 384})
+                    "k_sb_wgrad<3, 1>": 2.0 * 492000 * 384 * 128, "k_sb_gemm_n128<4, 1,": 2.0 * 196608 * 128 * 128,
+                    "k_sb_gemm_n128<12, 1,": 2.0 * 65536 * 384 * 128, "k_sb_gemm_n128<4, 3,": 2.0 * 492000 * 128 * 384})
 cnt = {}
 SUB = "grug" if GROUPED else "gru"    # the passes of tools/profile_all.sh: <dir>/gru_c, gru_t (single layer), grug_c, grug_t (grouped)
 for f in glob.glob(os.path.join(d, SUB + "_c", "**", "*counter_collection.csv"), recursive=True):
@@ -40,8 +43,13 @@ for k, fl in KERNELS.items():
             e["frac_of_bf16_pipe_div_6"] = round(fl / dur[k] / (2500e12 / 6), 4)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         e["MfmaUtil_percent"] = round(100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 2)
-    out["kernels"][k + (" (grouped: 20 layers, 65 536 sequences, 4 096 workgroups per launch)" if GROUPED else "")] = e
-path = os.path.join(ROOT, "profiles", "r03_gru_mfma_counters.json")
+    tag = ""
+    if GROUPED:
+        tag = " (492 000 rows)" if "gemm" in k else " (grouped: 20 layers, 65 536 sequences, 4 096 workgroups per launch)"
+    elif "k_sb_gemm_n128<12" in k:
+        tag = " (65 536 rows, in place)"
+    out["kernels"][k + tag] = e
+path = os.path.join(ROOT, "profiles", "r04_gru_mfma_counters.json")
 if GROUPED and os.path.exists(path):   # appended to the single-layer record
     base = json.load(open(path))
     base["kernels"].update(out["kernels"])

@@ -1,5 +1,5 @@
-"""rocprofv3 --pmc csv outputs -> profiles/r03_tick_pmc.json (packed LiDAR rows: the launch the rollout issues) or, with
---layout fp32, profiles/r03_tick_pmc_fp32.json (profile_tick.py --float-obs: the reference's fp32 rows); bench.py attaches them
+"""rocprofv3 --pmc csv outputs -> profiles/r04_tick_pmc.json (packed LiDAR rows: the launch the rollout issues) or, with
+--layout fp32, profiles/r04_tick_pmc_fp32.json (profile_tick.py --float-obs: the reference's fp32 rows); bench.py attaches them
 as roofline_packed_rows.traffic / roofline.traffic.
 
   python tools/pmc_summary.py <dir-with-counter-csvs> [--us-per-launch X] [--num-envs N] [--layout packed|fp32]
@@ -41,5 +41,5 @@ if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     out["fetch_bytes_corrected_x2"] = int(avg["FETCH_SIZE"] * 1024 * 2)
     out["write_bytes"] = int(avg["WRITE_SIZE"] * 1024)
     out["traffic_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_bytes"]
-json.dump(out, open(os.path.join(ROOT, "profiles", "r03_tick_pmc.json" if layout == "packed" else "r03_tick_pmc_fp32.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r04_tick_pmc.json" if layout == "packed" else "r04_tick_pmc_fp32.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -1,6 +1,6 @@
 # Re-creates every rocprofv3 record under profiles/ (run on the GPU box: gpurun -- "bash tools/profile_all.sh"; then, here,
-# python tools/collect_profiles.py gpurun_out/r3final).  --pmc passes are separate runs with no tracing domain beside them.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/r3final && mkdir -p $O
+# python tools/collect_profiles.py gpurun_out/r4final).  --pmc passes are separate runs with no tracing domain beside them.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/r4final && mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_cfg2 -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-kernel-probes > $O/bench_cfg2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_cfg3 -- python3 bench.py --config cfg3 --steps 2 --warmup 0 --no-cpu-baseline --no-kernel-probes > $O/bench_cfg3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tick -- python3 tools/profile_tick.py --episodes 2 > $O/tick.log 2>&1

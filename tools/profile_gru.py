@@ -23,17 +23,25 @@ if "--grouped" in sys.argv:
     Bs = [3280] * 18 + [3248] * 2          # 9 mini-batches of 410 episodes and one of 406, actor and critic each
     xs = [torch.randn(T, b, 128, device=dev, requires_grad=True) for b in Bs]
     h0s = [torch.zeros(1, b, 128, device=dev) for b in Bs]
-    for rep in range(3):
-        outs = ops.gru_multi(xs, h0s, [gm] * len(Bs), grouped=True)
-        torch.autograd.backward([o.sum() for o in outs])
+    for mode in ("fp32", "split_bf16"):    # k_gru_seq_fwd2 / bwd2, then k_gru_seq_fwd_sb / bwd_sb (the default)
+        ops.SEQ_MODE = mode
+        for rep in range(3):
+            outs = ops.gru_multi(xs, h0s, [gm] * len(Bs), grouped=True)
+            torch.autograd.backward([o.sum() for o in outs])
+    with torch.no_grad():                  # the update's 384-input product (dgi W_ih: 492 000 rows) on the split-bf16 GEMM
+        dg, W3 = torch.randn(Kr, 384, device=dev), w(128, 384)
+        for rep in range(10):
+            ops.split_linear(dg, W3)
     torch.cuda.synchronize()
     print("done (grouped)")
     sys.exit(0)
 x = torch.randn(T, B, 128, device=dev, requires_grad=True)
 h0 = torch.zeros(1, B, 128, device=dev)
-for rep in range(4):   # k_gru_seq_fwd + k_gru_seq_bwd + k_wgrad (the sequence mode of the update)
-    out, _ = ops.gru(x, h0, gm)
-    out.backward(torch.randn_like(out))
+for mode in ("fp32", "split_bf16"):
+    ops.SEQ_MODE = mode
+    for rep in range(4):   # k_gru_seq_fwd + k_gru_seq_bwd + k_wgrad (the sequence mode of the update)
+        out, _ = ops.gru(x, h0, gm)
+        out.backward(torch.randn_like(out))
 xr, hr = torch.randn(1, Br, 128, device=dev), torch.randn(1, Br, 128, device=dev)
 with torch.no_grad():
     for rep in range(20):  # k_gru_cell (one rollout step, fp32 MFMA: the evaluator's path and runtime.matmul: fp32)
