@@ -2272,13 +2272,25 @@ __global__ __launch_bounds__(RB_TPB) void k_relu_bwd_colsum(int64_t R, int F, co
     }
 }
 
-__global__ void k_colsum_reduce(int nblk, int F, const float *__restrict__ part, float *__restrict__ colsum) {
-    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (idx >= F) return;
+// colsum[f] = sum over the partial blocks, f64, fixed order: 32 columns x 8 slices of the blocks per workgroup -- a wave instruction reads
+// 128 contiguous bytes of two blocks (one wave per column walked the blocks with a 4 F-byte stride: 64 cache lines per instruction, 16 us
+// behind every ReLU-backward pass)
+__global__ __launch_bounds__(256) void k_colsum_reduce(int nblk, int F, const float *__restrict__ part, float *__restrict__ colsum) {
+    __shared__ double red[8][32];
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, f = blockIdx.x * 32 + c;
     double s = 0.0;
-    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * F + idx];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) colsum[idx] = (float)s;
+    if (f < F) {
+#pragma unroll 4
+        for (int b = sl; b < nblk; b += 8) s += (double)part[(size_t)b * F + f];
+    }
+    red[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && f < F) {
+        double t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; k++) t += red[k][c];
+        colsum[f] = (float)t;
+    }
 }
 
 // ---- skinny weight gradient: C [NS][F] = S^T X over R rows, S [R][NS] with NS <= 16 -----------------------------------------
@@ -2864,7 +2876,7 @@ int relu_bwd_colsum(int64_t R, int32_t F, const float *gout, int64_t g_row_strid
     const int grid = want < RB_BLOCKS ? (int)want : RB_BLOCKS;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_relu_bwd_colsum, dim3(grid), dim3(RB_TPB), 0, st, R, (int)F, gout, g_row_stride >> 2, y, y_row_stride >> 2, gin, (float *)workspace);
-    hipLaunchKernelGGL(k_colsum_reduce, dim3((F + 3) / 4), dim3(256), 0, st, grid, (int)F, (const float *)workspace, colsum);
+    hipLaunchKernelGGL(k_colsum_reduce, dim3((F + 31) / 32), dim3(256), 0, st, grid, (int)F, (const float *)workspace, colsum);
     return (int)hipGetLastError();
 }
 
