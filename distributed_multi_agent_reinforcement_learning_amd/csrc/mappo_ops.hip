@@ -6,6 +6,7 @@
 // registers read back with v_readlane (or come through scalar loads): no LDS, no barriers (section "relation message + mean").
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>

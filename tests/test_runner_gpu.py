@@ -333,3 +333,46 @@ def test_one_rank_rccl_smoke():
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["steps"] == 8 * 10 and j["calls"] == 2 and j["on_bucket"] and j["identity"], j     # one per epoch + the explicit call
     assert j["grad_nonzero"] > 0 and j["moved"] > 0 and j["finite"], j
+
+
+def test_device_reset_issued_ahead_equals_inline_reset(tmp_path):
+    """Pursuit_Env.prefetch_reset with the device resetter: the next episode's reset kernels run on the side stream (under the PPO update
+    in the Trainer) and reset() only waits for them -- same maps, same initial conditions, same episode as the inline reset; an injected
+    initial condition after the prefetch is refused; a resume bundle written while a reset is pending carries the state BEFORE it."""
+    from distributed_multi_agent_reinforcement_learning_amd.pursuit_env import Pursuit_Env
+    from distributed_multi_agent_reinforcement_learning_amd.trainer import Trainer
+    cfg = small_cfg(tmp_path, **{"runtime.device_reset": True})
+    acts = torch.randint(0, 9, (6, 8, 4), dtype=torch.int32, device="cuda")
+    seqs = []
+    for prefetch in (False, True):
+        env = Pursuit_Env(cfg, num_envs=8, seeds=list(range(40, 48)))
+        seq = []
+        for ep in range(3):
+            env.reset()
+            obs = env.observe(); env.attacker_step()
+            for t in range(6):
+                env.tick(acts[t], obs, torch.zeros(8, 4, device="cuda"))
+            seq.append((env.sim.grid.clone(), env.sim.defs.clone(), env.sim.eva.clone(), env.sim.target.clone(), obs["p_state"].clone()))
+            if prefetch:
+                env.prefetch_reset()
+                busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")   # work on the main stream beside it
+                if ep == 1:
+                    with pytest.raises(RuntimeError, match="already run"):
+                        env.reset(init={"grid": None})
+        seqs.append(seq)
+    for a, b in zip(*seqs):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # Trainer: a bundle saved after iterate() (reset pending) resumes into the same third iteration
+    a = Trainer(cfg)
+    a.iterate(); a.iterate()
+    assert a.env._dev_prefetch is not None
+    a.save_resume(str(tmp_path / "resume_dev.pt"))
+    a.iterate()
+    b = Trainer(cfg)
+    b.iterate()                                   # b has its own pending reset when the bundle arrives: it is dropped
+    b.load_resume(str(tmp_path / "resume_dev.pt"))
+    b.iterate()
+    assert b.total_steps == a.total_steps
+    assert torch.equal(a.env.sim.grid, b.env.sim.grid) and torch.equal(a.env.sim.target, b.env.sim.target) and torch.equal(a.env.sim.rn[:, 0], b.env.sim.rn[:, 0])
+    for (k, p), (_, q) in zip(a.agent.actor.state_dict().items(), b.agent.actor.state_dict().items()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), k
