@@ -26,6 +26,28 @@ int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const 
     return MO_ERR_BAD_ARG;
 }
 
+int64_t sb_gemm_masked_workspace(int32_t N) { return N > 0 ? (int64_t)1024 * N * 4 : 0; }   // one row of partial sums per workgroup (<= CUs)
+
+int sb_gemm_masked(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *M, int64_t ldm,
+                   int32_t mask_cols, float *Y, int64_t ldy, float *colsum, void *workspace, void *stream) {
+    if (R < 0 || !X || !W || !M || !Y || !colsum || !workspace || ldx < K || ldw < K || ldy < N || ldm < N) return MO_ERR_BAD_ARG;
+    if (mask_cols < 0 || mask_cols > N || (mask_cols & 127)) return MO_ERR_BAD_ARG;
+    if ((ldx & 3) || (ldw & 3) || (ldy & 3) || (ldm & 3) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 15) || ((uintptr_t)M & 15) ||
+        ((uintptr_t)colsum & 15) || ((uintptr_t)workspace & 15))
+        return MO_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) return (int)hipMemsetAsync(colsum, 0, (size_t)N * 4, st);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    if (cus > 1024) return MO_ERR_BAD_ARG;
+    float *part = (float *)workspace;
+    const int mt = mask_cols / 128;
+    if (N == 256 && K == 128) return launch_sb_gemm<4, 2, SBG_MASK_OPT_256>(R, X, ldx, W, ldw, nullptr, M, ldm, Y, ldy, 0, st, mt, part, colsum);
+    if (N == 384 && K == 128) return launch_sb_gemm<4, 3, SBG_MASK_OPT_384>(R, X, ldx, W, ldw, nullptr, M, ldm, Y, ldy, 0, st, mt, part, colsum);
+    if (N == 128 && K == 384) return launch_sb_gemm<12, 1, SBG_MASK_OPT_K384>(R, X, ldx, W, ldw, nullptr, M, ldm, Y, ldy, 0, st, mt, part, colsum);
+    return MO_ERR_BAD_ARG;
+}
+
 int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *addend,
                  int64_t lda, float *Y, int64_t ldy, void *stream) {
     return sb_gemm(R, 128, K, X, ldx, W, ldw, bias, relu, addend, lda, Y, ldy, stream);

@@ -15,10 +15,14 @@
 // OPT (bit mask; the product launches 3): 1 = the addend rows of a tile are requested BEFORE its matrix phase (round 3 loaded them
 // in the epilogue: one exposed HBM latency per 32 rows, 138 us against 47 us for the rollout's in-place semantic layer at 65 536
 // rows); 2 = the two waves of a SIMD (w and w + 4) run out of phase -- one splits and stages the next tile while the other
-// multiplies, as in k_sb_wgrad -- instead of all eight waves staging, then all multiplying.
+// multiplies, as in k_sb_wgrad -- instead of all eight waves staging, then all multiplying;  4 = the ReLU-backward form of an input
+// gradient (sb_gemm_masked): `addend` is not added but read as a MASK -- outputs of the first mask_tiles 128-column blocks are kept
+// where it is positive, zeroed elsewhere -- and the column sums of the result (the bias gradient of the layer whose ReLU this is)
+// leave the kernel as one row of partial sums per workgroup (fixed order: k_sb_colsum_reduce adds them deterministically).
 template <int KC, int NT, int OPT = 3>   // inputs / 32, outputs / 128
 __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__restrict__ X, int64_t ldx, const float *__restrict__ W, int64_t ldw,
-                                                      const float *__restrict__ bias, const float *addend, int64_t lda, float *Y, int64_t ldy, int relu) {
+                                                      const float *__restrict__ bias, const float *addend, int64_t lda, float *Y, int64_t ldy, int relu,
+                                                      int mask_tiles, float *__restrict__ colsum_part) {
     extern __shared__ uint4 sbg_tile[];                 // [buffer][piece][chunk][row half][lane]
     constexpr int IMG = 3 * KC * 2 * 64, UPW = KC / 4;  // uint4 per image; (chunk, half) blocks staged per wave and iteration
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, gq = l >> 4;
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
         const float *rw = W + (size_t)(16 * (w + 8 * t) + i) * ldw + 8 * gq;
 #pragma unroll
         for (int c = 0; c < KC; c++) sb_split8(*(const float4 *)(rw + 32 * c), *(const float4 *)(rw + 32 * c + 4), wg[t][c]);
-        b4[t] = bias ? *(const float4 *)(bias + 16 * (w + 8 * t) + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b4[t] = !(OPT & 4) && bias ? *(const float4 *)(bias + 16 * (w + 8 * t) + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int64_t n_it = (R + 31) / 32;
     float4 pf[UPW][2];
@@ -61,11 +65,14 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
     if (it + gridDim.x < n_it) fetch(it + gridDim.x);
     lds_barrier();
     int cur = 0;
+    float4 cs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) cs[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (; it < n_it; it += gridDim.x) {
         const uint4 *tb = sbg_tile + cur * IMG + l;
         f32x4 acc[NT][2];
         float4 a4[NT][2];
-        if ((OPT & 1) && addend) {   // in flight during the matrix phase
+        if ((OPT & 1) && addend) {   // in flight during the matrix phase (OPT & 4: the mask; tiles beyond mask_tiles are loaded and ignored)
 #pragma unroll
             for (int rt = 0; rt < 2; rt++) {
                 const int64_t row = it * 32 + rt * 16 + i;
@@ -116,6 +123,18 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
         }
         if (!(OPT & 2) || w >= 4) next_tile();
         // D tile: lane (i, gq), register q -> output 16 (w + 8 t) + 4 gq + q of row i of the half
+        if constexpr ((OPT & 4) && !(OPT & 1)) {
+            // the mask of the whole tile is requested at once, in registers the matrix phase has just released (the barrier keeps the
+            // compiler from hoisting the loads into that phase, where they do not fit)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) {
+                const int64_t row = it * 32 + rt * 16 + i;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    a4[t][rt] = row < R && t < mask_tiles ? *(const float4 *)(addend + row * lda + 16 * (w + 8 * t) + 4 * gq) : make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+        }
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
             const int64_t row = it * 32 + rt * 16 + i;
@@ -123,12 +142,22 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
                     const int col = 16 * (w + 8 * t) + 4 * gq;
-                    float4 v = make_float4(acc[t][rt][0] + b4[t].x, acc[t][rt][1] + b4[t].y, acc[t][rt][2] + b4[t].z, acc[t][rt][3] + b4[t].w);
-                    if (addend) {
-                        if (!(OPT & 1)) a4[t][rt] = *(const float4 *)(addend + row * lda + col);
-                        v.x += a4[t][rt].x; v.y += a4[t][rt].y; v.z += a4[t][rt].z; v.w += a4[t][rt].w;
+                    float4 v;
+                    if constexpr (OPT & 4) {
+                        v = make_float4(acc[t][rt][0], acc[t][rt][1], acc[t][rt][2], acc[t][rt][3]);
+                        if (t < mask_tiles) {
+                            v.x = a4[t][rt].x > 0.f ? v.x : 0.f; v.y = a4[t][rt].y > 0.f ? v.y : 0.f;
+                            v.z = a4[t][rt].z > 0.f ? v.z : 0.f; v.w = a4[t][rt].w > 0.f ? v.w : 0.f;
+                        }
+                        cs[t].x += v.x; cs[t].y += v.y; cs[t].z += v.z; cs[t].w += v.w;
+                    } else {
+                        v = make_float4(acc[t][rt][0] + b4[t].x, acc[t][rt][1] + b4[t].y, acc[t][rt][2] + b4[t].z, acc[t][rt][3] + b4[t].w);
+                        if (addend) {
+                            if (!(OPT & 1)) a4[t][rt] = *(const float4 *)(addend + row * lda + col);
+                            v.x += a4[t][rt].x; v.y += a4[t][rt].y; v.z += a4[t][rt].z; v.w += a4[t][rt].w;
+                        }
+                        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     }
-                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     *(float4 *)(Y + row * ldy + col) = v;
                 }
             }
@@ -136,11 +165,36 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
         lds_barrier();
         cur ^= 1;
     }
+    if constexpr (OPT & 4) {   // this workgroup's column sums: the 16 row lanes of a column group fold, lane i = 0 stores
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                cs[t].x += __shfl_xor(cs[t].x, m); cs[t].y += __shfl_xor(cs[t].y, m);
+                cs[t].z += __shfl_xor(cs[t].z, m); cs[t].w += __shfl_xor(cs[t].w, m);
+            }
+            if (i == 0) *(float4 *)(colsum_part + (size_t)blockIdx.x * (128 * NT) + 16 * (w + 8 * t) + 4 * gq) = cs[t];
+        }
+    }
+}
+
+// out[f] = sum over the workgroups' partial rows, in order (one thread per column, four independent chains)
+__global__ void k_sb_colsum_reduce(int n_parts, int F, const float *__restrict__ parts, float *__restrict__ out) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= n_parts; p += 4) {
+        a0 += parts[(size_t)p * F + f]; a1 += parts[(size_t)(p + 1) * F + f];
+        a2 += parts[(size_t)(p + 2) * F + f]; a3 += parts[(size_t)(p + 3) * F + f];
+    }
+    for (; p < n_parts; p++) a0 += parts[(size_t)p * F + f];
+    out[f] = (a0 + a1) + (a2 + a3);
 }
 
 template <int KC, int NT, int OPT>
 int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
-                   float *Y, int64_t ldy, int relu, hipStream_t st) {
+                   float *Y, int64_t ldy, int relu, hipStream_t st, int mask_tiles = 0, float *colsum_part = nullptr, float *colsum = nullptr) {
     constexpr int lds = 2 * 3 * KC * 2 * 64 * 16;
     static std::once_flag once;   // the evaluator's thread may launch concurrently with the trainer's
     static hipError_t attr_rc = hipSuccess;
@@ -150,7 +204,9 @@ int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const int64_t n_it = (R + 31) / 32;
     const int grid = n_it < cus ? (int)n_it : cus;
-    hipLaunchKernelGGL((k_sb_gemm_n128<KC, NT, OPT>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu);
+    hipLaunchKernelGGL((k_sb_gemm_n128<KC, NT, OPT>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, mask_tiles,
+                       colsum_part);
+    if constexpr (OPT & 4) hipLaunchKernelGGL(k_sb_colsum_reduce, dim3((128 * NT + 127) / 128), dim3(128), 0, st, grid, 128 * NT, colsum_part, colsum);
     return (int)hipGetLastError();
 }
 
@@ -158,6 +214,10 @@ int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64
 //   128 <- 384: 366 / 416 (OPT 0) -> 298 / 391 (OPT 2);   128 <- 256: 253 / 315 -> 213 (OPT 2) / 277 (OPT 3);   128 <- 128: 123 (OPT 0) /
 //   210 -> 180 (OPT 1);   256 <- 128: 263 / 363 -> 223 (OPT 2) / 311 (OPT 1);   384 <- 128: 363 / 516 -> 310 (OPT 2) / 516 (OPT 0).
 // The early addend request costs registers the 384-input and 384-output variants do not have (it spills there).
+// the masked (ReLU-backward) forms: see tools/microbench/sb_gemm_lab.hip
+// (492 000 rows, us, OPT 4 / 5 / 6 / 7: 256 <- 128: 329 / 316 / 307 / 327;  384 <- 128: 552 / 560 / 573 / 574;  128 <- 384: 450 / 467 / 423 / 488)
+constexpr int SBG_MASK_OPT_256 = 6, SBG_MASK_OPT_384 = 4, SBG_MASK_OPT_K384 = 6;
+
 template <int KC, int NT>
 int launch_sb_gemm_best(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
                         float *Y, int64_t ldy, int relu, hipStream_t st) {

@@ -649,8 +649,18 @@ class _RolloutState:
                 self.policy_step()
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # a background evaluator may launch on its own stream meanwhile
-            self.policy_step()
+        # The cyclic collector must not run while the stream captures: what it frees may be another agent's graphs or their private
+        # pool, and releasing those inside a capture aborts the process (torch.cuda.graph collects once on entry; an allocation-count
+        # threshold can still trip mid-capture).
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # a background evaluator may launch on its own stream meanwhile
+                self.policy_step()
+        finally:
+            if gc_was_on:
+                gc.enable()
         for t, k in zip(live, keep):
             t.copy_(k)
         return g

@@ -83,7 +83,8 @@ class DHGN(nn.Module):
         R, P = p.shape[0], p.shape[1]
         E, ind = self.embedding_dim, self.input_dim
         agg0 = self.AGG_layers["AGG_vertex_0"]
-        emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True)                       # one GEMM (+relu epilogue) for the three relations
+        link = ops.ReluLink()    # emb feeds the semantic layer only: its relu' and bias gradient ride in that layer's input gradient
+        emb = ops.linear(m3, agg0.weight, agg0.bias, relu=True, y_link=link)          # one GEMM (+relu epilogue) for the three relations
         # semantic_layer([p, emb0, emb1, emb2]) without materialising the concatenation (:284-303)
         Ws = self.semantic_layer.weight
         # the position part (K = 4) first, the embedding part accumulates INTO it (beta = 1, no copy of the addend)
@@ -93,7 +94,7 @@ class DHGN(nn.Module):
             torch.addmm(self.semantic_layer.bias, p2, Ws[:, :ind].t(), out=o2)
             h0 = o2.addmm_(e2, Ws[:, ind:].t())
         else:
-            h0 = ops.linear(e2, Ws[:, ind:], ops.linear_skinny(p2, Ws[:, :ind], self.semantic_layer.bias), consume_addend=True)
+            h0 = ops.linear(e2, Ws[:, ind:], ops.linear_skinny(p2, Ws[:, :ind], self.semantic_layer.bias), consume_addend=True, x_link=link)
         return h0.reshape(R, P, E)
 
     def encoder_pair_train(self, p, e, o, adj_p, adj_e, adj_o, q_div=1):
@@ -109,7 +110,7 @@ class DHGN(nn.Module):
         """hist: sequence of `depth` tensors (R,P,E), hop k = hist[k] (k = 0 is the most recent)."""
         if self.depth == 0:
             return h0
-        h, cat = h0, None
+        h, cat, link = h0, None, None
         for k in range(self.depth):
             aggk, fk = self.AGG_layers[f"AGG_fcra_{k}"], self.FCRA_layers[k]
             # matmul(normalize(adj or ones, p=1), hist[k]): one pass, the history slice read in place (hist is stored data)
@@ -117,7 +118,8 @@ class DHGN(nn.Module):
             last = k == self.depth - 1
             # FCRA_k([relu(AGG_k(nb)) | h]) as one K = 2E GEMM whose operand halves are written in place by their producers
             # (ops.fcra_hop); the last hop of a rollout lands in the static storage
-            h, cat = ops.fcra_hop(nb, h, cat, aggk.weight, aggk.bias, fk.weight, fk.bias, last, out if last else None)
+            # (each hop's output feeds the next hop only: `link` hands its relu' to that hop's input gradient)
+            h, cat, link = ops.fcra_hop(nb, h, cat, aggk.weight, aggk.bias, fk.weight, fk.bias, last, out if last else None, link)
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):

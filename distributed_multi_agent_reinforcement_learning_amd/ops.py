@@ -81,6 +81,9 @@ def load_library():
         L.wgrad_split_tn2.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, vp, vp]
         L.fcra_neighbour_mean.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, vp, vp, i64, vp]
         L.fcra_neighbour_mean_multi.argtypes = [i32, vp, i32, i32, i32, i32, i64, i64, i64, i64, vp, i64, i32, i64, vp]
+        L.sb_gemm_masked_workspace.argtypes = [i32]
+        L.sb_gemm_masked_workspace.restype = i64
+        L.sb_gemm_masked.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp]
         L.relu_bwd_colsum_workspace.argtypes = [i32]
         L.relu_bwd_colsum_workspace.restype = i64
         L.relu_bwd_colsum.argtypes = [i64, i32, vp, i64, vp, i64, vp, vp, vp, vp]
@@ -820,10 +823,11 @@ class _Linear(torch.autograd.Function):
     """x W^T + b whose weight gradient runs in the split-K MFMA kernel (wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu, consume_addend):
+    def forward(ctx, x, W, b, relu, consume_addend, x_link=None, y_link=None):
         ctx.bias_kind = 0 if b is None else (1 if b.dim() == 1 else 2)
         ctx.b_shape = None if b is None else b.shape
         ctx.relu = relu
+        ctx.x_link, ctx.y_link = x_link, (y_link if relu else None)
         inplace = bool(consume_addend and ctx.bias_kind == 2 and b.is_contiguous() and b.shape == x.shape[:-1] + (W.shape[0],))
         if inplace:
             ctx.mark_dirty(b)
@@ -837,17 +841,28 @@ class _Linear(torch.autograd.Function):
         db = None
         want_db = bool(ctx.bias_kind and ctx.needs_input_grad[2])
         if ctx.relu:  # relu'(pre-activation) from the saved output; with a 1-D bias its gradient comes out of the same pass
-            if want_db and ctx.bias_kind == 1:
+            if ctx.y_link is not None and ctx.y_link.db is not None:
+                # the consumer's input-gradient GEMM applied relu' and summed the columns (ReluLink)
+                if want_db and ctx.bias_kind == 1:
+                    db = ctx.y_link.take().view(-1, W.shape[0]).sum(0)
+            elif want_db and ctx.bias_kind == 1:
                 g, db = relu_bwd_colsum(g, y)
             else:
                 g = torch.ops.aten.threshold_backward(g, y, 0.0)
         g2 = g.reshape(-1, W.shape[0])
         x2 = x.reshape(-1, W.shape[1])
-        dx = input_grad(g2, W).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            fused = input_grad_masked(g2, W, x2, W.shape[1]) if ctx.x_link is not None else None
+            if fused is not None:
+                dx, ctx.x_link.db = fused
+            else:
+                dx = input_grad(g2, W)
+            dx = dx.reshape(x.shape)
         dW = wgrad(g2, x2) if ctx.needs_input_grad[1] else None
         if want_db and db is None:
             db = g2.sum(0) if ctx.bias_kind == 1 else g.reshape(ctx.b_shape)
-        return dx, dW, db, None, None
+        return dx, dW, db, None, None, None, None
 
 
 def input_grad(g2, W):
@@ -860,13 +875,58 @@ def input_grad(g2, W):
     return torch.mm(g2, W)
 
 
-def linear(x, W, b=None, out=None, relu=False, consume_addend=False):
+class ReluLink:
+    """Hand-over of a ReLU layer's backward to the ONE layer that consumes its output y (the update's relu(Linear) -> Linear chains,
+    DHGN/mappo_parallel.py:148-233).  Autograd runs threshold_backward and the bias sum as passes of their own over d y; here the
+    consumer's input-gradient GEMM applies relu'(y) in its epilogue and sums the columns on the way out (input_grad_masked: y is the
+    consumer's saved input).  The producer is built with `y_link=link`, the consumer with `x_link=link`; in backward the consumer
+    stores the column sums in `db` and returns the MASKED gradient, and the producer, finding `db` set, skips its own pass.  When the
+    consumer cannot fuse (shape, mode), `db` stays None and both sides behave as without a link.  y must have no other consumer:
+    autograd would add the other gradient to a masked one."""
+    __slots__ = ("db",)
+
+    def __init__(self):
+        self.db = None
+
+    def take(self):
+        db, self.db = self.db, None
+        return db
+
+
+MASKED_GRAD_SHAPES = {(256, 128), (384, 128), (128, 384)}   # (inputs of the layer = columns of the gradient, outputs)
+MASKED_GRAD_MIN_ROWS = 4096
+RELU_LINK = os.environ.get("MAPPO_RELU_LINK", "1") != "0"   # A/B switch (tools/ab_relu_link.py): off = the separate relu' / bias-sum passes
+
+
+def input_grad_masked(g2, W, y, mask_cols):
+    """(g2 W) * (y > 0) on the first mask_cols columns, and the column sums of the result (include/mappo_ops.h sb_gemm_masked):
+    the input gradient of a Linear layer (W: (outputs, inputs)) whose input y (rows, inputs) came out of a ReLU, with that ReLU's
+    backward and the bias gradient behind it.  -> (gradient (rows, inputs), sums (inputs,)), or None where the kernel does not apply."""
+    n_out, n_in = W.shape
+    if (not RELU_LINK or PROJ_MODE != "split_bf16" or (n_in, n_out) not in MASKED_GRAD_SHAPES or not g2.is_cuda or g2.dim() != 2 or y.dim() != 2
+            or g2.shape[0] < MASKED_GRAD_MIN_ROWS or y.shape != (g2.shape[0], n_in) or g2.dtype != torch.float32 or y.dtype != torch.float32):
+        return None
+    Wt = W.detach().t().contiguous()
+    for t in (g2, y):
+        if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+            return None
+    L = load_library()
+    R = g2.shape[0]
+    out = torch.empty((R, n_in), dtype=torch.float32, device=g2.device)
+    cs = torch.empty(n_in, dtype=torch.float32, device=g2.device)
+    ws = torch.empty(L.sb_gemm_masked_workspace(n_in), dtype=torch.uint8, device=g2.device)
+    _check(L.sb_gemm_masked(R, n_in, n_out, _ptr(g2), g2.stride(0), _ptr(Wt), Wt.stride(0), _ptr(y), y.stride(0), int(mask_cols), _ptr(out), out.stride(0),
+                            _ptr(cs), _ptr(ws), _stream()), "sb_gemm_masked")
+    return out, cs
+
+
+def linear(x, W, b=None, out=None, relu=False, consume_addend=False, x_link=None, y_link=None):
     """F.linear(x, W, b), optionally followed by relu (W may be a column slice of a larger weight; b a bias or a full
     addend); under autograd the weight gradient uses wgrad.  out (no autograd): written in place.  consume_addend: see
-    _linear_fwd (b must be a temporary: it becomes the result)."""
+    _linear_fwd (b must be a temporary: it becomes the result).  x_link / y_link: ReluLink."""
     if torch.is_grad_enabled() and (W.requires_grad or x.requires_grad or (b is not None and b.requires_grad)):
         assert out is None
-        return _Linear.apply(x, W, b, relu, consume_addend)
+        return _Linear.apply(x, W, b, relu, consume_addend, x_link, y_link)
     return _linear_fwd(x, W, b, out, relu, consume_addend)
 
 
@@ -950,7 +1010,7 @@ class _FcraHop(torch.autograd.Function):
     [d agg | d h], split-K MFMA weight gradients.  nb is stored data (no gradient)."""
 
     @staticmethod
-    def forward(ctx, nb, h, cat, Wagg, bagg, Wf, bf, last, out, box):
+    def forward(ctx, nb, h, cat, Wagg, bagg, Wf, bf, last, out, box, h_link=None):
         E = Wf.shape[0]
         rows = h.numel() // E
         nb2 = nb.reshape(rows, E)
@@ -976,6 +1036,10 @@ class _FcraHop(torch.autograd.Function):
         # the version counter the saved view `dst` shares with it although its own columns are never touched again
         ctx.cat, ctx.y = cat, dst
         ctx.h_shape = h.shape
+        # h_link: h is the previous hop's ReLU output (the right half of cat) and this hop its only consumer; y_link: the same
+        # offer to whoever consumes this hop's output
+        ctx.h_link, ctx.y_link = h_link, ReluLink()
+        box.append(ctx.y_link)
         return dst.reshape(h.shape) if out is None else out
 
     @staticmethod
@@ -988,20 +1052,33 @@ class _FcraHop(torch.autograd.Function):
             g2 = block2d(g)
         except AssertionError:
             g2 = g.reshape(rows, E).contiguous()
-        gin, dbf = relu_bwd_colsum(g2, y)
-        dcat = input_grad(gin, Wf)                     # [d agg | d h]
+        if ctx.y_link.db is not None:                  # the consumer masked the gradient and summed its columns (ReluLink)
+            gin, dbf = g2, ctx.y_link.take()
+        else:
+            gin, dbf = relu_bwd_colsum(g2, y)
+        # [d agg | d h]; relu' of the AGG layer -- and of the previous hop's FCRA layer, whose output the right half of cat is --
+        # in the GEMM's epilogue, the two bias gradients its column sums
+        fused = input_grad_masked(gin, Wf, cat, 2 * E if ctx.h_link is not None else E)
+        if fused is not None:
+            dcat, cs = fused
+            ga, dbagg = dcat[:, :E], cs[:E]
+            if ctx.h_link is not None:
+                ctx.h_link.db = cs[E:]
+        else:
+            dcat = input_grad(gin, Wf)
+            ga, dbagg = relu_bwd_colsum(dcat[:, :E], cat[:, :E])
         dWf = wgrad(gin, cat)
-        ga, dbagg = relu_bwd_colsum(dcat[:, :E], cat[:, :E])
         dWagg = wgrad(ga, nb2)
         d_h = dcat[:, E:].reshape(ctx.h_shape)         # a view (column block)
-        return None, d_h, None, dWagg, dbagg, dWf, dbf, None, None, None
+        return None, d_h, None, dWagg, dbagg, dWf, dbf, None, None, None, None
 
 
-def fcra_hop(nb, h, cat, Wagg, bagg, Wf, bf, last, out=None):
-    """-> (h', cat'): see _FcraHop.  cat' is the buffer whose right half h' is (None after the last hop / when `out` is given)."""
+def fcra_hop(nb, h, cat, Wagg, bagg, Wf, bf, last, out=None, h_link=None):
+    """-> (h', cat', link): see _FcraHop.  cat' is the buffer whose right half h' is (None after the last hop / when `out` is given);
+    link: the ReluLink of h' (pass it as h_link to the next hop, its only consumer)."""
     box = []
-    y = _FcraHop.apply(nb, h, cat, Wagg, bagg, Wf, bf, bool(last), out, box)
-    return y, box[0]
+    y = _FcraHop.apply(nb, h, cat, Wagg, bagg, Wf, bf, bool(last), out, box, h_link)
+    return y, box[0], box[1]
 
 
 FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel

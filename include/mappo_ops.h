@@ -254,6 +254,14 @@ int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float 
  * x W_ih^T + b_ih, (256, 128) the input gradient of an FCRA layer. */
 int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *C,
             int64_t ldc, float *Y, int64_t ldy, void *stream);
+/* The input gradient of a Linear layer whose INPUT is the output of a ReLU layer, with that ReLU's backward and the bias gradient of
+ * the layer in front of it in the same pass (autograd's threshold_backward + sum(0) of DHGN/mappo_parallel.py:148-233's relu(Linear)
+ * chains):  Y = (X W^T) * (M > 0) on the first mask_cols columns (a multiple of 128; the others are plain X W^T),  colsum[N] = column
+ * sums of Y.  M [R][N] (row stride ldm) is the saved ReLU output; (N, K) in {(256, 128), (384, 128), (128, 384)}.  The column sums are
+ * reduced from per-workgroup partials in `workspace` (>= sb_gemm_masked_workspace(N) bytes) in a fixed order: same bits every run. */
+int64_t sb_gemm_masked_workspace(int32_t N);
+int sb_gemm_masked(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *M, int64_t ldm,
+                   int32_t mask_cols, float *Y, int64_t ldy, float *colsum, void *workspace, void *stream);
 
 /*
  * PPO clipped-surrogate policy loss and clipped value loss of one mini-batch with their gradients

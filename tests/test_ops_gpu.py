@@ -907,11 +907,77 @@ def test_input_grad_with_strided_gradient_matches_f64(N, K, mode):
     assert dx.shape == (R, K) and e <= 2.0 * e_lib + 1e-6, (e, e_lib)
 
 
+@pytest.mark.parametrize("n_in,n_out,mask_cols", [(256, 128, 128), (256, 128, 256), (384, 128, 384), (128, 384, 128)])
+def test_input_gradient_with_the_relu_backward_in_its_epilogue(n_in, n_out, mask_cols):
+    """ops.input_grad_masked (sb_gemm_masked): (g W) * (y > 0) on the first mask_cols columns and its column sums -- autograd's
+    threshold_backward and bias sum of the relu(Linear) in front -- against f64, with g and y column blocks of wider matrices, a ragged
+    row count, and exact zeros / negative zeros / denormals in y (relu' is 0 there: threshold_backward keeps y > 0 only).  The sums are
+    deterministic: two runs agree bit for bit."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(n_in + mask_cols)
+    R = 70000 + 19
+    gw, yw = torch.randn(R, n_out + 8, device="cuda"), torch.randn(R, n_in + 12, device="cuda")
+    g, y = gw[:, 4:4 + n_out], yw[:, 8:8 + n_in]
+    y[::3, ::5] = 0.0
+    y[1::7, 1::4] = -0.0
+    y[2::11, 2::3] = 1e-42
+    W = torch.randn(n_out, n_in, device="cuda") * 0.2
+    modes = ops.matmul_modes()
+    ops.set_matmul_mode("split_bf16")
+    try:
+        with torch.no_grad():
+            dx, cs = ops.input_grad_masked(g, W, y, mask_cols)
+            dx2, cs2 = ops.input_grad_masked(g, W, y, mask_cols)
+            plain = ops.input_grad(g, W)
+        assert ops.input_grad_masked(g[:100], W, y[:100], mask_cols) is None      # below the row threshold: the caller's unfused path
+    finally:
+        ops.restore_matmul_modes(modes)
+    keep = torch.ones(R, n_in, device="cuda", dtype=torch.bool)
+    keep[:, :mask_cols] = y[:, :mask_cols] > 0
+    ref = (g.double() @ W.double()) * keep
+    assert dx.shape == (R, n_in) and cs.shape == (n_in,)
+    assert torch.equal(dx, torch.where(keep, plain, torch.zeros_like(plain)))          # the same product, masked
+    assert float((dx.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    assert float((cs.double() - ref.sum(0)).abs().max()) < 2e-6 * float(ref.abs().sum(0).max())
+    assert torch.equal(dx, dx2) and torch.equal(cs, cs2)
+
+
+def test_relu_link_gives_the_gradients_of_the_unlinked_layers():
+    """ops.ReluLink: relu(Linear) -> Linear with the ReLU's backward handed to the consumer's input gradient equals the same two layers
+    without the link (every gradient; the bias gradient to summation order), and a link nobody fills changes nothing."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(5)
+    rows, E = 30000, 128
+    m3 = torch.randn(rows, 3, E, device="cuda")
+    gout = torch.randn(rows, E, device="cuda")
+    base = [torch.randn(E, E, device="cuda") * 0.2, torch.randn(E, device="cuda") * 0.2, torch.randn(E, 3 * E, device="cuda") * 0.1]
+    modes = ops.matmul_modes()
+    ops.set_matmul_mode("split_bf16")
+    grads = {}
+    try:
+        for linked in (False, True, "unused"):
+            Wa, ba, Ws = [t.clone().requires_grad_(True) for t in base]
+            x = m3.clone().requires_grad_(True)
+            link = ops.ReluLink() if linked else None
+            emb = ops.linear(x, Wa, ba, relu=True, y_link=link)
+            h = ops.linear(emb.reshape(rows, 3 * E), Ws, None, x_link=link if linked is True else None)
+            (h * gout).sum().backward()
+            grads[linked] = [t.grad for t in (Wa, ba, Ws, x)]
+            assert link is None or link.db is None                               # consumed by the producer
+    finally:
+        ops.restore_matmul_modes(modes)
+    for a, b, c in zip(grads[False], grads[True], grads["unused"]):
+        assert torch.equal(a, c)
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), a.shape
+    assert torch.equal(grads[False][3], grads[True][3]) and torch.equal(grads[False][0], grads[True][0])
+
+
 @pytest.mark.parametrize("mode", ["split_bf16", "fp32"])
 def test_fcra_hop_forward_and_backward_match_f64(mode):
     """ops.fcra_hop (one DHGN.fcra hop, DHGN/mappo_parallel.py:204-233: h' = relu(FCRA([relu(AGG(nb)) | h]))) chained twice, forward
     and every gradient against an f64 torch evaluation, at a row count above the kernels' thresholds (split-bf16 GEMMs / hipBLASLt,
-    k_relu_bwd_colsum on column blocks, k_sb_wgrad / k_wgrad).  ReLU's derivative is discontinuous: an activation within rounding
+    the ReLU backward in the input gradient's epilogue (ReluLink) / k_relu_bwd_colsum on column blocks, k_sb_wgrad / k_wgrad).  ReLU's
+    derivative is discontinuous: an activation within rounding
     noise of zero may fall on either side in fp32 and f64, which moves a weight gradient by a whole row's contribution -- so the f64
     gradients are evaluated with the ReLU masks of the product's own forward pass (read from its operand buffers)."""
     from distributed_multi_agent_reinforcement_learning_amd import ops
@@ -930,8 +996,8 @@ def test_fcra_hop_forward_and_backward_match_f64(mode):
     modes = ops.matmul_modes()
     ops.set_matmul_mode(mode)
     try:
-        h1, cat1 = ops.fcra_hop(nb[0], h0g, cat0, params[0], params[2], params[4], params[6], False)
-        h2, _ = ops.fcra_hop(nb[1], h1, cat1, params[1], params[3], params[5], params[7], True)
+        h1, cat1, link = ops.fcra_hop(nb[0], h0g, cat0, params[0], params[2], params[4], params[6], False)
+        h2, _, _ = ops.fcra_hop(nb[1], h1, cat1, params[1], params[3], params[5], params[7], True, h_link=link)
         (h2 * gout).sum().backward()
     finally:
         ops.restore_matmul_modes(modes)

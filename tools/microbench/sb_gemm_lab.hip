@@ -303,6 +303,58 @@ int main(int argc, char **argv) {
                 printf("N=%d K=%d rows=%lld  %-26s %8.1f us  %5.2f TB/s %6.1f TF | in place += : %8.1f us %5.2f TB/s\n", N, K, (long long)R, sbg_lab_name(variant), us,
                        bytes / us * 1e-6, flop / us * 1e-6, us_add, (bytes + (double)R * N * 4.0) / us_add * 1e-6);
             }
+            // the ReLU-backward form (OPT bit 4): Y = (X W^T) * (M > 0) on the first mask_cols columns, column sums from per-workgroup partials
+            if ((N == 256 && K == 128) || (N == 384 && K == 128) || (N == 128 && K == 384)) {
+                std::vector<float> hm(hy.size());
+                for (size_t q = 0; q < hm.size(); q++) hm[q] = ((q * 2246822519u) >> 7) % 3 ? (float)(q % 17 + 1) : 0.f;   // a third of the units inactive
+                CK(hipMemcpy(C, hm.data(), hm.size() * 4, hipMemcpyHostToDevice));
+                float *part, *cs;
+                CK(hipMalloc(&part, 1024 * N * 4)); CK(hipMalloc(&cs, N * 4));
+                const int mcols = N == 256 ? 128 : N;          // first FCRA hop: only the aggregate half is behind a ReLU
+                std::vector<float> y0(hy.size());
+                for (int opt = 4; opt < 8; opt++) {
+                    auto run = [&]() -> int {
+#define LAB_M(KC, NT)                                                                                                                  \
+                        switch (opt) {                                                                                                \
+                            case 4: return launch_sb_gemm<KC, NT, 4>(R, X, K, W, K, nullptr, C, N, Y, N, 0, 0, mcols / 128, part, cs); \
+                            case 5: return launch_sb_gemm<KC, NT, 5>(R, X, K, W, K, nullptr, C, N, Y, N, 0, 0, mcols / 128, part, cs); \
+                            case 6: return launch_sb_gemm<KC, NT, 6>(R, X, K, W, K, nullptr, C, N, Y, N, 0, 0, mcols / 128, part, cs); \
+                            case 7: return launch_sb_gemm<KC, NT, 7>(R, X, K, W, K, nullptr, C, N, Y, N, 0, 0, mcols / 128, part, cs); \
+                        }
+                        if (N == 256) { LAB_M(4, 2) }
+                        if (N == 384) { LAB_M(4, 3) }
+                        if (N == 128) { LAB_M(12, 1) }
+#undef LAB_M
+                        return -1;
+                    };
+                    CK(hipMemset(Y, 0, hy.size() * 4));
+                    if (run()) { printf("masked OPT=%d: launch error\n", opt); continue; }
+                    CK(hipDeviceSynchronize());
+                    const float us = time_us(run);
+                    CK(hipMemcpy(hy.data(), Y, hy.size() * 4, hipMemcpyDeviceToHost));
+                    std::vector<float> hcs(N);
+                    CK(hipMemcpy(hcs.data(), cs, N * 4, hipMemcpyDeviceToHost));
+                    double worst = 0.0, worst_cs = 0.0, cs_scale = 0.0;
+                    for (int s2 = 0; s2 < 97; s2++) {
+                        const int64_t r = (s2 * 7919 + (s2 == 96 ? R - 1 : 0)) % R;
+                        for (int n = 0; n < N; n++) {
+                            double ref = 0.0;
+                            for (int k = 0; k < K; k++) ref += (double)hx[(size_t)r * K + k] * (double)hw[(size_t)n * K + k];
+                            if (n < mcols && !(hm[(size_t)r * N + n] > 0.f)) ref = 0.0;
+                            worst = fmax(worst, fabs(ref - (double)hy[(size_t)r * N + n]));
+                        }
+                    }
+                    std::vector<double> col(N, 0.0), cabs(N, 0.0);
+                    for (int64_t r = 0; r < R; r++)
+                        for (int n = 0; n < N; n++) { col[n] += hy[(size_t)r * N + n]; cabs[n] += fabs(hy[(size_t)r * N + n]); }
+                    for (int n = 0; n < N; n++) { worst_cs = fmax(worst_cs, fabs(col[n] - (double)hcs[n])); cs_scale = fmax(cs_scale, cabs[n]); }
+                    size_t bad = 0;
+                    if (opt == 4) y0 = hy; else for (size_t q = 0; q < hy.size(); q++) bad += memcmp(&y0[q], &hy[q], 4) != 0;
+                    printf("N=%d K=%d rows=%lld  masked OPT=%d (mask on %d columns) %8.1f us  %5.2f TB/s | max |err| vs f64 %.3g, column sums off by %.3g of %.3g (sum |.|), "
+                           "%zu elements differ from OPT=4\n", N, K, (long long)R, opt, mcols, us, ((double)R * (K + 2 * N) * 4.0) / us * 1e-6, worst, worst_cs, cs_scale, bad);
+                }
+                CK(hipFree(part)); CK(hipFree(cs));
+            }
             // in place accumulate (beta = 1) through the product entry point
             CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(B)); CK(hipFree(Y)); CK(hipFree(C));
         }
