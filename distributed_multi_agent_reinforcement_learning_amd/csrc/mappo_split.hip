@@ -39,7 +39,7 @@ int sb_gemm_masked(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx,
     if (R == 0) return (int)hipMemsetAsync(colsum, 0, (size_t)N * 4, st);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    if (cus > 1024) return MO_ERR_BAD_ARG;
+    if (cus > 512) return MO_ERR_BAD_ARG;          // (the workspace holds 1024 rows: up to two workgroups per CU)
     float *part = (float *)workspace;
     const int mt = mask_cols / 128;
     if (N == 256 && K == 128) return launch_sb_gemm<4, 2, SBG_MASK_OPT_256>(R, X, ldx, W, ldw, nullptr, M, ldm, Y, ldy, 0, st, mt, part, colsum);

@@ -192,6 +192,8 @@ __global__ void k_sb_colsum_reduce(int n_parts, int F, const float *__restrict__
     out[f] = (a0 + a1) + (a2 + a3);
 }
 
+static int g_sbg_wgs_per_cu = 0;   // lab override (tools/microbench/sb_gemm_lab.hip); 0 = the default below
+
 template <int KC, int NT, int OPT>
 int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
                    float *Y, int64_t ldy, int relu, hipStream_t st, int mask_tiles = 0, float *colsum_part = nullptr, float *colsum = nullptr) {
@@ -203,7 +205,10 @@ int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const int64_t n_it = (R + 31) / 32;
-    const int grid = n_it < cus ? (int)n_it : cus;
+    // persistent workgroups per CU: the 128 x 128 variant (114-119 registers) fits two, whose phases interleave -- from 131 072 rows up
+    // that pays (492 000 rows: 133 -> 121 us plain, 177 -> 152 us in place; 1 476 000: 361 -> 341 / 567 -> 490); below, one
+    const int wpc = g_sbg_wgs_per_cu ? g_sbg_wgs_per_cu : (KC * NT == 4 && R >= 131072 ? 2 : 1);
+    const int grid = n_it < (int64_t)cus * wpc ? (int)n_it : cus * wpc;
     hipLaunchKernelGGL((k_sb_gemm_n128<KC, NT, OPT>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, mask_tiles,
                        colsum_part);
     if constexpr (OPT & 4) hipLaunchKernelGGL(k_sb_colsum_reduce, dim3((128 * NT + 127) / 128), dim3(128), 0, st, grid, 128 * NT, colsum_part, colsum);
@@ -224,5 +229,8 @@ int launch_sb_gemm_best(int64_t R, const float *X, int64_t ldx, const float *W, 
     constexpr int PLAIN = (KC == 4 && NT == 1) ? 0 : 2;
     constexpr int ADD = KC == 12 ? 2 : (KC == 8 ? 3 : (NT == 3 ? 0 : 1));
     if (addend) return launch_sb_gemm<KC, NT, ADD>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
+    // 128 x 128 beyond the Infinity Cache (the update's AGG layer over three relations, 1 476 000 rows): the phase shift wins there
+    // (405 -> 341 us; at 492 000 rows 121 against 124)
+    if constexpr (KC == 4 && NT == 1) if (R >= 786432) return launch_sb_gemm<4, 1, 2>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
     return launch_sb_gemm<KC, NT, PLAIN>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
 }

@@ -237,6 +237,7 @@ int main(int argc, char **argv) {
     std::vector<int64_t> sizes;
     for (int i = 1; i < argc; i++) sizes.push_back(atoll(argv[i]));
     if (sizes.empty()) sizes = {65536, 196608, 492000};
+    if (getenv("SBG_WPC")) g_sbg_wgs_per_cu = atoi(getenv("SBG_WPC"));   // persistent workgroups per CU (register budget permitting)
     const int shapes[][2] = {{128, 384}, {128, 256}, {128, 128}, {256, 128}, {384, 128}};
     for (auto &nk : shapes) {
         const int N = nk[0], K = nk[1];
