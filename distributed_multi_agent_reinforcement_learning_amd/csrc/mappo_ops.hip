@@ -2226,6 +2226,71 @@ __global__ void k_nbr_mean(NbrArgs a, NbrJobs jobs, const float *__restrict__ ad
     }
 }
 
+// E = 128, P <= 8: one WAVE per row (environment step), 16 bytes per lane -- lane (q, hf) owns the feature quad q of the output agents
+// 4 hf .. 4 hf + 3; both halves read the P neighbour quads (the second read of an address is an L1 hit), the weights are wave-uniform
+// (v_readlane) and selected per half.  Against the lane-per-feature form above (4-byte accesses, 3.1 / 3.7 TB/s actor / critic at the
+// update's 61 500 rows): tools/nbr_probe.py.
+__global__ __launch_bounds__(256) void k_nbr_mean4(NbrArgs a, NbrJobs jobs, const float *__restrict__ adj) {
+    const mo_nbr_job &job = jobs.j[blockIdx.y];
+    const float *__restrict__ za = job.z_actor, *__restrict__ zc = job.z_critic;
+    float *__restrict__ out_a = job.out_actor, *__restrict__ out_c = job.out_critic;
+    const int P = a.P, lane = threadIdx.x & 63, q = lane & 31, hf = lane >> 5;
+    constexpr int E = 128;
+    const float4 b4 = job.bias ? *(const float4 *)(job.bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv_p = 1.f / fmaxf((float)P, 1e-12f);
+    const bool relu = a.relu != 0;
+    auto put = [&](float *dst, float4 v) {
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4 *)dst = v;
+    };
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < a.R; r += gridDim.x * 4) {
+        const int n = r / a.T, t = r - n * a.T;
+        if (out_a) {
+            const float *zr = za + (size_t)n * a.za_es + (size_t)t * a.za_ts + 4 * q;
+            float4 z[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) z[j] = j < P ? *(const float4 *)(zr + (size_t)j * E) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // lane l = i P + j holds adj[i][j] / max(sum_j |adj[i][j]|, eps)   (the same arithmetic as k_nbr_mean)
+            const float av = lane < P * P ? adj[(size_t)r * a.adj_rs + lane] : 0.f;
+            const int li = lane / P < P ? lane / P : P - 1;
+            float nrm = 0.f;
+            for (int j = 0; j < P; j++) nrm += fabsf(__shfl(av, li * P + j));
+            const float w = av / fmaxf(nrm, 1e-12f);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (j < P) {
+                        const float w_lo = rl_f(w, k * P + j), w_hi = 4 + k < P ? rl_f(w, (4 + k) * P + j) : 0.f;
+                        const float wv = hf ? w_hi : w_lo;
+                        acc.x = __builtin_fmaf(wv, z[j].x, acc.x); acc.y = __builtin_fmaf(wv, z[j].y, acc.y);
+                        acc.z = __builtin_fmaf(wv, z[j].z, acc.z); acc.w = __builtin_fmaf(wv, z[j].w, acc.w);
+                    }
+                const int i = 4 * hf + k;
+                if (i < P) put(out_a + ((size_t)r * P + i) * a.out_ld + 4 * q, acc);
+            }
+        }
+        if (out_c) {
+            const float *zr = zc + (size_t)n * a.zc_es + (size_t)t * a.zc_ts + 4 * q;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (j < P) {
+                    const float4 v = *(const float4 *)(zr + (size_t)j * E);
+                    acc.x = __builtin_fmaf(inv_p, v.x, acc.x); acc.y = __builtin_fmaf(inv_p, v.y, acc.y);
+                    acc.z = __builtin_fmaf(inv_p, v.z, acc.z); acc.w = __builtin_fmaf(inv_p, v.w, acc.w);
+                }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = 4 * hf + k;
+                if (i < P) put(out_c + ((size_t)r * P + i) * a.out_ld + 4 * q, acc);
+            }
+        }
+    }
+}
+
 // ---- ReLU backward + bias gradient in one pass ------------------------------------------------------------------------------
 // gin = gout * [y > 0] (aten::threshold_backward on the saved output) and colsum[f] = sum_r gin[r][f] (the bias gradient of the
 // Linear in front of the ReLU): autograd reads gin a second time for the sum (756 MB per mini-batch at DHGN's AGG layer);
@@ -2859,6 +2924,18 @@ int fcra_neighbour_mean_multi(int32_t n_jobs, const mo_nbr_job *jobs, int32_t R,
     }
     if (R == 0) return 0;
     NbrArgs a{R, P, E, T, relu, za_episode_stride, za_step_stride, zc_episode_stride, zc_step_stride, adj_row_stride, out_stride};
+    if (E == 128 && P <= 8 && !(out_stride & 3) && !(za_episode_stride & 3) && !(za_step_stride & 3) && !(zc_episode_stride & 3) && !(zc_step_stride & 3)) {
+        bool aligned = true;
+        for (int k = 0; k < n_jobs; k++) {
+            const mo_nbr_job &m = jobs[k];
+            aligned = aligned && !(((uintptr_t)m.z_actor | (uintptr_t)m.z_critic | (uintptr_t)m.bias | (uintptr_t)m.out_actor | (uintptr_t)m.out_critic) & 15);
+        }
+        if (aligned) {
+            const int per4 = 4096 / n_jobs, blocks = (R + 3) / 4;
+            hipLaunchKernelGGL(k_nbr_mean4, dim3(blocks < per4 ? blocks : per4, n_jobs), dim3(256), 0, (hipStream_t)stream, a, a_jobs, adj);
+            return (int)hipGetLastError();
+        }
+    }
     const int per = 16384 / n_jobs, grid = R < per ? R : per;
     if (P <= 8) hipLaunchKernelGGL(k_nbr_mean<8>, dim3(grid, n_jobs), dim3(E), 0, (hipStream_t)stream, a, a_jobs, adj);
     else hipLaunchKernelGGL(k_nbr_mean<16>, dim3(grid, n_jobs), dim3(E), 0, (hipStream_t)stream, a, a_jobs, adj);

@@ -368,7 +368,7 @@ class MAPPO:
         for g0 in range(0, len(starts), G):
             group = [(n0, min(n0 + self.mini_batch_size, N)) for n0 in starts[g0:g0 + G]]
             segs.zero()
-            xs, mods = [], []
+            xs, mods, links = [], [], []
             for k, (n0, n1) in enumerate(group):
                 obs, hist_a, hist_c = self._minibatch_inputs(batch, o_static, n0, n1)
                 with segs.use(k):
@@ -376,8 +376,9 @@ class MAPPO:
                     mods += [_gru_weights(self.actor.GRU), _gru_weights(self.critic.GRU)]
                 rows = (n1 - n0) * T * P
                 xs += [emb_a.reshape(rows, self.actor.rnn_input_dim), emb_c.reshape(rows, self.critic.rnn_input_dim)]
+                links += [getattr(emb_a, "relu_link", None), getattr(emb_c, "relu_link", None)]   # depth > 0: the last hop's ReLU
             h0s = [torch.zeros(m.num_layers, x.shape[0] // T, H, dtype=x.dtype, device=x.device) for x, m in zip(xs, mods)]
-            feats = ops.gru_multi(xs, h0s, mods, agents=P, steps=T, grouped=True)
+            feats = ops.gru_multi(xs, h0s, mods, agents=P, steps=T, grouped=True, x_links=links)
             losses = []
             for k, (n0, n1) in enumerate(group):
                 mb = n1 - n0

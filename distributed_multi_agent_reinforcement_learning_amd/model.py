@@ -120,6 +120,7 @@ class DHGN(nn.Module):
             # (ops.fcra_hop); the last hop of a rollout lands in the static storage
             # (each hop's output feeds the next hop only: `link` hands its relu' to that hop's input gradient)
             h, cat, link = ops.fcra_hop(nb, h, cat, aggk.weight, aggk.bias, fk.weight, fk.bias, last, out if last else None, link)
+        h.relu_link = link       # for a caller that is the ONLY consumer of h (the update hands it to the first GRU layer)
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):
@@ -358,7 +359,8 @@ def sequence_forward_pair(actor, critic, obs, hist_a, hist_c, batch, steps):
     else:
         h0 = [torch.zeros(m.num_layers, batch * P, m.rnn_hidden_dim, dtype=emb_a.dtype, device=emb_a.device) for m in (actor, critic)]
         fa, fc = ops.gru_multi([emb_a.reshape(batch * steps * P, actor.rnn_input_dim), emb_c.reshape(batch * steps * P, critic.rnn_input_dim)],
-                               h0, [actor.GRU, critic.GRU], agents=P, steps=steps)
+                               h0, [actor.GRU, critic.GRU], agents=P, steps=steps,
+                               x_links=[getattr(emb_a, "relu_link", None), getattr(emb_c, "relu_link", None)])
         feat_a, feat_c = fa.reshape(steps, batch, P, actor.rnn_hidden_dim), fc.reshape(steps, batch, P, critic.rnn_hidden_dim)
     return pair_heads(actor, critic, feat_a, feat_c)
 

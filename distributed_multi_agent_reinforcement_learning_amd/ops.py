@@ -1408,10 +1408,11 @@ class _GRULayerMulti(torch.autograd.Function):
     """The same layer of several independent GRUs (the actor's and the critic's, for one or several mini-batches: own weights, own
     inputs, own number of sequences; same T and row order) with the recurrences of all of them in ONE persistent launch each way
     (gru_seq_fwd_multi / gru_seq_bwd_multi); per network the arithmetic is that of _GRULayer's persistent path.
-    args: T, Bs (sequences per network), agents, then per network (x, h0, w_ih, w_hh, b_ih, b_hh)."""
+    args: T, Bs (sequences per network), agents, x_links (None, or per network the ReluLink of an input that came out of a ReLU and
+    feeds this layer only -- its relu' and bias sum then ride in the input gradient), then per network (x, h0, w_ih, w_hh, b_ih, b_hh)."""
 
     @staticmethod
-    def forward(ctx, T, Bs, agents, *ts):
+    def forward(ctx, T, Bs, agents, x_links, *ts):
         L = load_library()
         n = len(ts) // 6
         H = ts[3].shape[1]
@@ -1438,6 +1439,7 @@ class _GRULayerMulti(torch.autograd.Function):
             saved += [x, h0, w_ih, whh, out, save]
         _seq_fwd(L, arr, n, T, max(Bs), H, int(agents))
         ctx.dims, ctx.agents, ctx.n = (T, tuple(Bs)), int(agents), n
+        ctx.x_links = x_links
         ctx.x_shapes = [ts[6 * k].shape for k in range(n)]
         if need:
             ctx.save_for_backward(*saved)
@@ -1471,15 +1473,24 @@ class _GRULayerMulti(torch.autograd.Function):
             a.B = B
             per.append((dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws))
         _seq_bwd(L, arr, n, T, max(Bs), H, ctx.agents)
-        grads = [None, None, None]
+        grads = [None, None, None, None]
         for k in range(n):
             x, h0, w_ih, w_hh, out, save = sv[6 * k: 6 * k + 6]
             dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws = per[k]
             B = Bs[k]
             dw_hh = _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H)
             I = x.shape[-1]
-            dw_ih = wgrad(dgi, x.reshape(T * B, I))
-            dx = input_grad(dgi, w_ih).reshape(ctx.x_shapes[k]) if ctx.needs_input_grad[3 + 6 * k] else None
+            x2 = x.reshape(T * B, I)
+            dw_ih = wgrad(dgi, x2)
+            dx = None
+            if ctx.needs_input_grad[4 + 6 * k]:
+                link = ctx.x_links[k] if ctx.x_links is not None else None
+                fused = input_grad_masked(dgi, w_ih, x2, I) if link is not None else None
+                if fused is not None:
+                    dx, link.db = fused
+                else:
+                    dx = input_grad(dgi, w_ih)
+                dx = dx.reshape(ctx.x_shapes[k])
             grads += [dx, dh0, dw_ih, dw_hh, db_ih, db_hh]
         return tuple(grads)
 
@@ -1510,12 +1521,12 @@ def _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H):
     return dw_hh
 
 
-def gru_multi(xs, h0s, modules, agents=0, steps=None, grouped=False):
+def gru_multi(xs, h0s, modules, agents=0, steps=None, grouped=False, x_links=None):
     """ops.gru for several independent GRU modules of one architecture (actor and critic, for one or -- `grouped` -- several
     mini-batches: the inputs may differ in their number of sequences): layer by layer, the recurrences of all of them in one launch
     (see _GRULayerMulti).  `modules` need only carry num_layers and the weight_* / bias_* attributes of torch.nn.GRU.  Returns the
     list of outputs (T, B_k, H) (no h_n: sequences start from the given h0 and the final state is out[-1]).  Shapes the persistent
-    kernels do not cover take ops.gru per module."""
+    kernels do not cover take ops.gru per module.  x_links: per input its ReluLink or None (see _GRULayerMulti)."""
     n = len(xs)
     if agents:
         assert xs[0].dim() == 2 and steps and all(x.shape[0] % (steps * agents) == 0 for x in xs)
@@ -1538,7 +1549,8 @@ def gru_multi(xs, h0s, modules, agents=0, steps=None, grouped=False):
         for k, m in enumerate(modules):
             ts += [inps[k], h0s[k][layer], getattr(m, f"weight_ih_l{layer}"), getattr(m, f"weight_hh_l{layer}"),
                    getattr(m, f"bias_ih_l{layer}"), getattr(m, f"bias_hh_l{layer}")]
-        inps = list(_GRULayerMulti.apply(T, tuple(Bs), int(agents) if layer == 0 else 0, *ts))
+        links = tuple(x_links) if layer == 0 and x_links is not None and any(l is not None for l in x_links) else None
+        inps = list(_GRULayerMulti.apply(T, tuple(Bs), int(agents) if layer == 0 else 0, links, *ts))
     return inps
 
 

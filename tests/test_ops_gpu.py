@@ -602,6 +602,28 @@ def test_fcra_neighbour_mean_matches_torch(P, T, relu):
     assert torch.equal(both[0], got_a) and torch.equal(both[1], got_c)
 
 
+@pytest.mark.parametrize("P,E", [(8, 128), (5, 128), (3, 128), (1, 128), (8, 256)])
+def test_fcra_neighbour_mean_at_size_into_a_column_block(P, E):
+    """fcra_mean at the update's row count (more rows than one pass of the grid), odd agent counts, and the result written into the
+    left half of an [agg | h] operand (row stride 2E): the wave-per-row kernel (E = 128, P <= 8) and the lane-per-feature kernel
+    (other widths) against f64; the right half of the operand stays untouched."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(P + E)
+    n, T, d = 150, 41, 3
+    R = n * T
+    buf = torch.randn(n, T + d, P, E, device="cuda")
+    z = buf[:, 2:2 + T]
+    adj = (torch.rand(R, P, P, device="cuda") < 0.5).float()
+    bias = torch.randn(E, device="cuda")
+    z64 = z.reshape(R, P, E).double()
+    cat = torch.full((2, R, P, 2 * E), 7.0, device="cuda")
+    ops.fcra_mean(z_actor=z, z_critic=z, adj=adj, bias=bias, relu=True, out=cat[..., :E])
+    for k, a in enumerate((adj, torch.ones_like(adj))):
+        want = torch.relu(torch.matmul(torch.nn.functional.normalize(a.double(), p=1, dim=-1), z64) + bias.double())
+        assert torch.allclose(cat[k, ..., :E].double(), want, rtol=1e-5, atol=1e-5)
+    assert bool((cat[..., E:] == 7.0).all())
+
+
 @pytest.mark.parametrize("T,n,P", [(37, 20, 8), (150, 7, 4), (5, 6, 8)])
 def test_gru_reads_encoder_row_order_in_place(T, n, P):
     """ops.gru(agents = P): the first layer's input given as the encoder's (episode, step, agent) rows equals the time-major

@@ -21,14 +21,14 @@ from tests.test_mappo_gpu import close, make_agent
 
 pytestmark = pytest.mark.gpu
 
-ENTRY_POINTS = ("wgrad_split_tn", "wgrad_tn", "relu_bwd_colsum", "wgrad_skinny", "sb_gemm")
+ENTRY_POINTS = ("wgrad_split_tn", "wgrad_tn", "relu_bwd_colsum", "wgrad_skinny", "sb_gemm", "sb_gemm_masked")
 
 
 @pytest.fixture
 def forced_kernels(monkeypatch):
     """every size threshold of the update's kernel routing at 1 + call counters on the library's entry points; restores the matmul mode"""
     from distributed_multi_agent_reinforcement_learning_amd import ops
-    for name in ("WGRAD_MIN_ROWS", "RELU_BWD_MIN_ROWS", "SKINNY_MIN_ROWS", "SORTED_ONES_MIN_QDIV"):
+    for name in ("WGRAD_MIN_ROWS", "RELU_BWD_MIN_ROWS", "SKINNY_MIN_ROWS", "SORTED_ONES_MIN_QDIV", "MASKED_GRAD_MIN_ROWS"):
         monkeypatch.setattr(ops, name, 1)
     L = ops.load_library()
     calls = {n: 0 for n in ENTRY_POINTS}
@@ -49,11 +49,14 @@ def forced_kernels(monkeypatch):
 
 def _expected_entry_points(E, mode):
     """the HIP entry points that must have been on the path for a fixture of embedding width E"""
-    want = {"relu_bwd_colsum", "wgrad_skinny"}
+    want = {"wgrad_skinny"}
     if E % 128 == 0:      # the MFMA weight-gradient kernels cover multiples of 128 features
         want.add("wgrad_split_tn" if mode == "split_bf16" else "wgrad_tn")
         if mode == "split_bf16":
             want.add("sb_gemm")
+    # ReLU backward + bias sums: in the input-gradient GEMM's epilogue (E = 128, split mode: every ReLU of the networks has such a
+    # consumer), else the separate pass
+    want.add("sb_gemm_masked" if E == 128 and mode == "split_bf16" else "relu_bwd_colsum")
     return want
 
 
