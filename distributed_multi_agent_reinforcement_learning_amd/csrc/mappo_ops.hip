@@ -1756,45 +1756,41 @@ MsgDims msg_dims(int R, int P, int K, int E, int din, int q_div, int adj_mode, i
 // same pass with autograd's tie rules: min / max send half the gradient to each side of an exact tie (inside the clip
 // range surr1 == surr2, and both halves reach the ratio), clamp passes the gradient on its closed range.
 constexpr int PPO_BLOCKS = 256;
-__global__ __launch_bounds__(256) void k_ppo_loss(long n, const float *lp_now, const float *ent, const float *lp_old, const float *adv,
-                                                  const float *active, const float *v_now, const float *v_old, const float *v_tgt,
-                                                  const float *active_sum, float eps, float ent_coef, int value_clip, float *g_lp,
-                                                  float *g_ent, float *g_v, double *partials) {
-    const float inv = 1.f / active_sum[0];
-    double sa = 0.0, sc = 0.0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const float act = active[i];
-        const float ratio = expf(lp_now[i] - lp_old[i]);
-        const float a = adv[i];
-        const float surr1 = ratio * a;
-        const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
-        const float surr2 = rc * a;
-        const float la = -fminf(surr1, surr2) - ent_coef * ent[i];
-        sa += (double)(la * act);
-        const bool inside = ratio >= 1.f - eps && ratio <= 1.f + eps;
-        const float w1 = surr1 < surr2 ? 1.f : (surr1 == surr2 ? 0.5f : 0.f);   // share of min() that flows to surr1
-        const float w2 = surr2 < surr1 ? 1.f : (surr1 == surr2 ? 0.5f : 0.f);   // ... to surr2 (reaches the ratio inside the clip range)
-        const float up = act * inv;                                               // d loss / d la
-        g_lp[i] = -up * (w1 + (inside ? w2 : 0.f)) * a * ratio;
-        g_ent[i] = -up * ent_coef;
-        const float eo = v_now[i] - v_tgt[i];
-        float lc, gv;
-        if (value_clip) {
-            const float d = v_now[i] - v_old[i];
-            const float dc = fminf(fmaxf(d, -eps), eps);
-            const float ec = (dc + v_old[i]) - v_tgt[i];
-            const float qa = ec * ec, qb = eo * eo;
-            lc = fmaxf(qa, qb);
-            const float wa = qa > qb ? 1.f : (qa == qb ? 0.5f : 0.f), wb = qb > qa ? 1.f : (qa == qb ? 0.5f : 0.f);
-            const bool din = d >= -eps && d <= eps;
-            gv = wa * 2.f * ec * (din ? 1.f : 0.f) + wb * 2.f * eo;
-        } else {
-            lc = eo * eo;
-            gv = 2.f * eo;
-        }
-        sc += (double)(lc * act);
-        g_v[i] = up * gv;
+struct PpoElem { float la, lc, g_lp, g_ent, g_v; };
+__device__ __forceinline__ PpoElem ppo_elem(float lp_now, float ent, float lp_old, float a, float act, float v_now, float v_old, float v_tgt, float inv,
+                                            float eps, float ent_coef, int value_clip) {
+    PpoElem o;
+    const float ratio = expf(lp_now - lp_old);
+    const float surr1 = ratio * a;
+    const float rc = fminf(fmaxf(ratio, 1.f - eps), 1.f + eps);
+    const float surr2 = rc * a;
+    o.la = -fminf(surr1, surr2) - ent_coef * ent;
+    const bool inside = ratio >= 1.f - eps && ratio <= 1.f + eps;
+    const float w1 = surr1 < surr2 ? 1.f : (surr1 == surr2 ? 0.5f : 0.f);   // share of min() that flows to surr1
+    const float w2 = surr2 < surr1 ? 1.f : (surr1 == surr2 ? 0.5f : 0.f);   // ... to surr2 (reaches the ratio inside the clip range)
+    const float up = act * inv;                                               // d loss / d la
+    o.g_lp = -up * (w1 + (inside ? w2 : 0.f)) * a * ratio;
+    o.g_ent = -up * ent_coef;
+    const float eo = v_now - v_tgt;
+    float gv;
+    if (value_clip) {
+        const float d = v_now - v_old;
+        const float dc = fminf(fmaxf(d, -eps), eps);
+        const float ec = (dc + v_old) - v_tgt;
+        const float qa = ec * ec, qb = eo * eo;
+        o.lc = fmaxf(qa, qb);
+        const float wa = qa > qb ? 1.f : (qa == qb ? 0.5f : 0.f), wb = qb > qa ? 1.f : (qa == qb ? 0.5f : 0.f);
+        const bool din = d >= -eps && d <= eps;
+        gv = wa * 2.f * ec * (din ? 1.f : 0.f) + wb * 2.f * eo;
+    } else {
+        o.lc = eo * eo;
+        gv = 2.f * eo;
     }
+    o.g_v = up * gv;
+    return o;
+}
+
+__device__ __forceinline__ void ppo_block_sums(double sa, double sc, double *partials) {
     __shared__ double red[2][256];
     red[0][threadIdx.x] = sa; red[1][threadIdx.x] = sc;
     __syncthreads();
@@ -1803,6 +1799,76 @@ __global__ __launch_bounds__(256) void k_ppo_loss(long n, const float *lp_now, c
         __syncthreads();
     }
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = red[0][0]; partials[2 * blockIdx.x + 1] = red[1][0]; }
+}
+
+__global__ __launch_bounds__(256) void k_ppo_loss(long n, const float *lp_now, const float *ent, const float *lp_old, const float *adv,
+                                                  const float *active, const float *v_now, const float *v_old, const float *v_tgt,
+                                                  const float *active_sum, float eps, float ent_coef, int value_clip, float *g_lp,
+                                                  float *g_ent, float *g_v, double *partials) {
+    const float inv = 1.f / active_sum[0];
+    double sa = 0.0, sc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float act = active[i];
+        const PpoElem e = ppo_elem(lp_now[i], ent[i], lp_old[i], adv[i], act, v_now[i], value_clip ? v_old[i] : 0.f, v_tgt[i], inv, eps, ent_coef, value_clip);
+        sa += (double)(e.la * act);
+        sc += (double)(e.lc * act);
+        g_lp[i] = e.g_lp; g_ent[i] = e.g_ent; g_v[i] = e.g_v;
+    }
+    ppo_block_sums(sa, sc, partials);
+}
+
+// The same loss from the policy's PROBABILITIES: torch.distributions.Categorical(prob) -- renormalisation, probs_to_logits' clamp to
+// [eps, 1 - eps], log_prob's gather and entropy() (DHGN/mappo_parallel.py:451-456) -- evaluated in registers in torch's op order, and
+// the gradient with respect to prob written straight out (autograd's rules: the clamp passes the gradient on its closed range).  One
+// launch instead of Categorical's ~16 element-wise kernels over (rows, A) and their backward.  prob / its gradient and the values are
+// read through 3-D views (index (i0, i1, i2) of the (mini-batch, T, P) rows): the heads' outputs are time-major.
+struct PpoView { long d1, d2, s0, s1, s2; };
+constexpr int PPO_MAX_A = 16;
+__global__ __launch_bounds__(256) void k_ppo_loss_prob(long n, int A, const float *__restrict__ prob, PpoView pv, const float *__restrict__ action,
+                                                       const float *lp_old, const float *adv, const float *active, const float *__restrict__ v_now, PpoView vv,
+                                                       const float *v_old, const float *v_tgt, const float *active_sum, float eps, float ent_coef,
+                                                       int value_clip, float *__restrict__ g_prob, float *__restrict__ g_v, double *partials) {
+    const float inv = 1.f / active_sum[0];
+    constexpr float P_EPS = 1.1920928955078125e-07f;      // torch.finfo(torch.float32).eps (clamp_probs)
+    double sa = 0.0, sc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long i2 = i % pv.d2, i01 = i / pv.d2, i1 = i01 % pv.d1, i0 = i01 / pv.d1;
+        const long po = i0 * pv.s0 + i1 * pv.s1 + i2 * pv.s2;
+        float p[PPO_MAX_A], l[PPO_MAX_A];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < PPO_MAX_A; k++) { p[k] = k < A ? prob[po + k] : 0.f; if (k < A) s += p[k]; }
+        const int a_idx = (int)action[i];
+        float lp = 0.f, plp = 0.f;
+#pragma unroll
+        for (int k = 0; k < PPO_MAX_A; k++)
+            if (k < A) {
+                p[k] = p[k] / s;                                              // Categorical.probs
+                l[k] = logf(fminf(fmaxf(p[k], P_EPS), 1.f - P_EPS));          // probs_to_logits
+                if (k == a_idx) lp = l[k];
+                plp += l[k] * p[k];
+            }
+        const float act = active[i];
+        const float vn = v_now[i0 * vv.s0 + i1 * vv.s1 + i2 * vv.s2];
+        const PpoElem e = ppo_elem(lp, -plp, lp_old[i], adv[i], act, vn, value_clip ? v_old[i] : 0.f, v_tgt[i], inv, eps, ent_coef, value_clip);
+        sa += (double)(e.la * act);
+        sc += (double)(e.lc * act);
+        g_v[i] = e.g_v;
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < PPO_MAX_A; k++)
+            if (k < A) {
+                const float c = fminf(fmaxf(p[k], P_EPS), 1.f - P_EPS);
+                const bool pass = p[k] >= P_EPS && p[k] <= 1.f - P_EPS;
+                const float gl = (k == a_idx ? e.g_lp : 0.f) - e.g_ent * p[k];   // d / d logits[k]: log_prob's gather, entropy's logits * probs
+                l[k] = (pass ? gl / c : 0.f) - e.g_ent * l[k];                    // d / d probs[k]
+                dot += l[k] * p[k];
+            }
+#pragma unroll
+        for (int k = 0; k < PPO_MAX_A; k++)
+            if (k < A) g_prob[po + k] = (l[k] - dot) / s;                        // through probs = prob / prob.sum(-1)
+    }
+    ppo_block_sums(sa, sc, partials);
 }
 
 __global__ void k_ppo_loss_finish(int nblk, const double *partials, const float *active_sum, float *losses) {
@@ -3010,6 +3076,23 @@ int ppo_loss_fwd_bwd(int64_t n, const float *logp_now, const float *entropy, con
     hipLaunchKernelGGL(k_ppo_loss, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, logp_now, entropy, logp_old, adv, active,
                        values_now, values_old, v_target, active_sum, epsilon, entropy_coef, (int)use_value_clip, grad_logp, grad_entropy,
                        grad_values, (double *)workspace);
+    hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)blocks, (const double *)workspace, active_sum, losses);
+    return (int)hipGetLastError();
+}
+
+int ppo_loss_prob_fwd_bwd(int64_t n, int32_t A, const float *prob, float *grad_prob, int64_t d1, int64_t d2, int64_t p_s0, int64_t p_s1, int64_t p_s2,
+                          const float *action, const float *logp_old, const float *adv, const float *active, const float *values_now, int64_t v_s0,
+                          int64_t v_s1, int64_t v_s2, const float *values_old, const float *v_target, const float *active_sum, float epsilon,
+                          float entropy_coef, int32_t use_value_clip, float *losses, float *grad_values, void *workspace, void *stream) {
+    if (n < 1 || A < 1 || A > PPO_MAX_A || d1 < 1 || d2 < 1 || (n % (d1 * d2)) || !prob || !grad_prob || !action || !logp_old || !adv || !active ||
+        !values_now || !v_target || !active_sum || !losses || !grad_values || !workspace || (use_value_clip && !values_old))
+        return MO_ERR_BAD_ARG;
+    long blocks = (n + 255) / 256;
+    if (blocks > PPO_BLOCKS) blocks = PPO_BLOCKS;
+    const PpoView pv{d1, d2, p_s0, p_s1, p_s2}, vv{d1, d2, v_s0, v_s1, v_s2};
+    hipLaunchKernelGGL(k_ppo_loss_prob, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n, (int)A, prob, pv, action, logp_old, adv, active,
+                       values_now, vv, values_old, v_target, active_sum, epsilon, entropy_coef, (int)use_value_clip, grad_prob, grad_values,
+                       (double *)workspace);
     hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)blocks, (const double *)workspace, active_sum, losses);
     return (int)hipGetLastError();
 }

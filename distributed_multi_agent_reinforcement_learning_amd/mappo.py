@@ -315,6 +315,11 @@ class MAPPO:
         return obs, hist_a, hist_c
 
     def _minibatch_losses(self, batch, adv, v_target, n0, n1, prob, values_now):
+        v_old = batch["v_n"][n0:n1, :-1] if self.use_value_clip else None
+        if ops.ppo_loss_prob_ok(prob, values_now.squeeze(-1)):
+            # Categorical(prob).log_prob / .entropy() (get_logprob_and_entropy, :451-456) evaluated inside the loss launch
+            return ops.ppo_loss_prob(prob, batch["a_n"][n0:n1], values_now.squeeze(-1), batch["a_logprob_n"][n0:n1], adv[n0:n1], batch["active"][n0:n1],
+                                     v_old, v_target[n0:n1], self.epsilon, self.entropy_coef, self.use_value_clip)
         dist = torch.distributions.Categorical(prob)      # get_logprob_and_entropy (:451-456)
         a_logprob_n_now, dist_entropy = dist.log_prob(batch["a_n"][n0:n1]), dist.entropy()
         return ops.ppo_loss(a_logprob_n_now, dist_entropy, values_now.squeeze(-1), batch["a_logprob_n"][n0:n1], adv[n0:n1],

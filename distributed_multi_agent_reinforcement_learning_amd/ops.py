@@ -15,7 +15,7 @@ ADJ_TENSOR, ADJ_ONES, ADJ_VALID, ADJ_BITS = 0, 1, 2, 3
 EXPORTS = ("dhgn_msg_agg_fwd", "dhgn_msg_agg3_fwd", "dhgn_msg_agg_bwd", "dhgn_msg_agg_bwd_workspace", "dhgn_msg_agg_ones_sorted_ok", "dhgn_msg_agg_ones_sorted_fwd",
            "dhgn_msg_agg_ones_sorted_bwd", "dhgn_msg_agg_ones_sorted_workspace", "gae_advnorm", "gae_advnorm_workspace", "categorical_sample",
            "categorical_sample_counter",
-           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "sb_gemm", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_split_fwd_multi", "gru_seq_split_bwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "wgrad_split_tn", "wgrad_split_tn2", "wgrad_split_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_workspace",
+           "gru_gates_fwd", "gru_gates_bwd", "gru_cell_fwd", "gru_cell_fwd_multi", "gru_cell_split_fwd_multi", "sb_gemm_n128", "sb_gemm", "gru_seq_fwd", "gru_seq_fwd_multi", "gru_seq_split_fwd_multi", "gru_seq_split_bwd_multi", "gru_seq_save_elems", "gru_seq_bwd", "gru_seq_bwd_multi", "gru_seq_bwd_workspace", "wgrad_tn", "wgrad_tn_workspace", "wgrad_split_tn", "wgrad_split_tn2", "wgrad_split_workspace", "rollout_record", "ppo_loss_fwd_bwd", "ppo_loss_prob_fwd_bwd", "ppo_loss_workspace",
            "mappo_ops_error_string")
 
 _lib = None
@@ -93,6 +93,7 @@ def load_library():
         L.rollout_record.argtypes = [i32, i32, vp, vp, vp, i32, vp]
         L.ppo_loss_workspace.restype = i64
         L.ppo_loss_fwd_bwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp]
+        L.ppo_loss_prob_fwd_bwd.argtypes = [i64, i32, vp, vp, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
         L.sb_split_diag.argtypes = [i64, vp, vp, vp]
         L.mappo_ops_error_string.argtypes = [C.c_int]
         L.mappo_ops_error_string.restype = C.c_char_p
@@ -895,7 +896,7 @@ class ReluLink:
 
 MASKED_GRAD_SHAPES = {(256, 128), (384, 128), (128, 384)}   # (inputs of the layer = columns of the gradient, outputs)
 MASKED_GRAD_MIN_ROWS = 4096
-RELU_LINK = os.environ.get("MAPPO_RELU_LINK", "1") != "0"   # A/B switch (tools/ab_relu_link.py): off = the separate relu' / bias-sum passes
+RELU_LINK = os.environ.get("MAPPO_RELU_LINK", "1") != "0"   # A/B switch (tools/ab_switch.py): off = the separate relu' / bias-sum passes
 
 
 def input_grad_masked(g2, W, y, mask_cols):
@@ -1108,6 +1109,54 @@ class _PPOLoss(torch.autograd.Function):
     def backward(ctx, ga, gc):
         (g,) = ctx.saved_tensors
         return g[0] * ga, g[1] * ga, g[2] * gc, None, None, None, None, None, None, None, None
+
+
+class _PPOLossProb(torch.autograd.Function):
+    """(actor_loss, critic_loss) of one mini-batch from the policy's probabilities: Categorical(prob).log_prob / .entropy() inside the
+    loss launch (ppo_loss_prob_fwd_bwd), which also writes the gradient with respect to prob."""
+
+    @staticmethod
+    def forward(ctx, prob, values_now, action, logp_old, adv, active, values_old, v_target, epsilon, entropy_coef, use_value_clip):
+        L = load_library()
+        _need_gpu(prob, "ppo_loss_prob")
+        A = prob.shape[-1]
+        d0, d1, d2 = prob.shape[:3]
+        n = d0 * d1 * d2
+        ts = [t.contiguous() for t in (action, logp_old, adv, active, v_target)]
+        vo = values_old.contiguous() if values_old is not None else None
+        assert all(t.numel() == n and t.dtype == torch.float32 for t in ts) and values_now.shape == prob.shape[:3]
+        dev = prob.device
+        asum = active.sum().reshape(1)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        g_prob = torch.empty_strided(prob.shape, prob.stride(), dtype=torch.float32, device=dev)    # the layout of prob (a time-major view)
+        g_v = torch.empty(values_now.shape, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.ppo_loss_workspace(), dtype=torch.uint8, device=dev)
+        ps, vs = prob.stride(), values_now.stride()
+        _check(L.ppo_loss_prob_fwd_bwd(n, A, _ptr(prob), _ptr(g_prob), d1, d2, ps[0], ps[1], ps[2], _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]),
+                                       _ptr(values_now), vs[0], vs[1], vs[2], _ptr(vo), _ptr(ts[4]), _ptr(asum), float(epsilon), float(entropy_coef),
+                                       int(bool(use_value_clip)), _ptr(losses), _ptr(g_v), _ptr(ws), _stream()), "ppo_loss_prob_fwd_bwd")
+        ctx.save_for_backward(g_prob, g_v)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, ga, gc):
+        g_prob, g_v = ctx.saved_tensors
+        return g_prob * ga, g_v * gc, None, None, None, None, None, None, None, None, None
+
+
+PPO_FROM_PROB = os.environ.get("MAPPO_PPO_FROM_PROB", "1") != "0"   # A/B switch: off = torch.distributions.Categorical + ppo_loss
+
+
+def ppo_loss_prob_ok(prob, values_now):
+    return (PPO_FROM_PROB and prob.is_cuda and prob.dtype == torch.float32 and prob.dim() == 4 and prob.stride(3) == 1 and 1 <= prob.shape[-1] <= 16
+            and values_now.dtype == torch.float32 and values_now.shape == prob.shape[:3] and prob.numel() > 0)
+
+
+def ppo_loss_prob(prob, action, values_now, logp_old, adv, active, values_old, v_target, epsilon, entropy_coef, use_value_clip=True):
+    """ppo_loss(Categorical(prob).log_prob(action), Categorical(prob).entropy(), ...) in one launch (DHGN/mappo_parallel.py:451-456,
+    :692-706; csrc/mappo_ops.hip k_ppo_loss_prob).  prob (mb, T, P, A), values_now (mb, T, P): any strides over the first three
+    dimensions (the heads' outputs are time-major views)."""
+    return _PPOLossProb.apply(prob, values_now, action, logp_old, adv, active, values_old, v_target, epsilon, entropy_coef, use_value_clip)
 
 
 def ppo_loss(logp_now, entropy, values_now, logp_old, adv, active, values_old, v_target, epsilon, entropy_coef, use_value_clip=True):

@@ -278,6 +278,15 @@ int ppo_loss_fwd_bwd(int64_t n, const float *logp_now, const float *entropy, con
                      const float *values_now, const float *values_old, const float *v_target, const float *active_sum, float epsilon,
                      float entropy_coef, int32_t use_value_clip, float *losses, float *grad_logp, float *grad_entropy, float *grad_values,
                      void *workspace, void *stream);
+/* The same losses from the policy's probabilities prob[.., A] (A <= 16): torch.distributions.Categorical(prob).log_prob(action) and
+ * .entropy() (DHGN/mappo_parallel.py:451-456: renormalisation, the clamp of probs_to_logits, the gather) are evaluated inside the pass
+ * and the gradient with respect to prob comes out instead of grad_logp / grad_entropy.  The n = d0 d1 d2 rows are indexed (i0, i1, i2);
+ * prob and grad_prob are read / written at i0 p_s0 + i1 p_s1 + i2 p_s2 (+ k, k < A), values_now at i0 v_s0 + i1 v_s1 + i2 v_s2 (strides in
+ * floats: the heads' outputs are time-major views); action (float-valued indices) and the other operands are dense in row order. */
+int ppo_loss_prob_fwd_bwd(int64_t n, int32_t A, const float *prob, float *grad_prob, int64_t d1, int64_t d2, int64_t p_s0, int64_t p_s1, int64_t p_s2,
+                          const float *action, const float *logp_old, const float *adv, const float *active, const float *values_now, int64_t v_s0,
+                          int64_t v_s1, int64_t v_s2, const float *values_old, const float *v_target, const float *active_sum, float epsilon,
+                          float entropy_coef, int32_t use_value_clip, float *losses, float *grad_values, void *workspace, void *stream);
 
 /*
  * Records one rollout tick into the replay buffer (MAPPO.run_episode's minibuffer.store_transition,

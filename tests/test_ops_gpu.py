@@ -297,6 +297,50 @@ def test_ppo_loss_matches_autograd_oracle(value_clip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("value_clip", [True, False])
+@pytest.mark.parametrize("A,sharp", [(9, 1.0), (9, 40.0), (5, 8.0), (16, 1.0), (1, 1.0)])
+def test_ppo_loss_from_probabilities_equals_the_categorical_route(A, sharp, value_clip):
+    """ops.ppo_loss_prob (Categorical(prob).log_prob / .entropy() inside the loss launch, gradient with respect to prob written out)
+    against torch.distributions.Categorical + ops.ppo_loss on the same time-major head outputs: both losses and the gradients that
+    reach the logits and the values.  sharp = 40 drives probabilities below finfo.eps and to 1 (probs_to_logits' clamp is active and
+    blocks the gradient there); rows with an inactive mask, exact ratio ties and both clip sides as in the test above."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(A + int(sharp))
+    T, mb, P = 150, 23, 8
+    logits = torch.randn((T, mb, P, A), generator=g, device="cuda") * sharp
+    vals = torch.randn((T, mb, P, 1), generator=g, device="cuda")
+    shape = (mb, T, P)
+    action = torch.randint(0, A, shape, generator=g, device="cuda").float()
+    with torch.no_grad():
+        lp0 = torch.distributions.Categorical(torch.softmax(logits, -1).permute(1, 0, 2, 3)).log_prob(action)
+    lp_old = lp0 + torch.randn(shape, generator=g, device="cuda") * 0.05
+    lp_old[::3] = lp0[::3]                                     # exact ties of min(surr1, surr2)
+    adv = torch.randn(shape, generator=g, device="cuda")
+    active = (torch.rand(shape, generator=g, device="cuda") > 0.1).float()
+    v_n = torch.randn((mb, T + 1, P), generator=g, device="cuda")
+    v_tgt = torch.randn(shape, generator=g, device="cuda")
+    eps, coef = 0.05, 0.05
+    res = []
+    for fused in (False, True):
+        z, v = logits.clone().requires_grad_(True), vals.clone().requires_grad_(True)
+        prob, values_now = torch.softmax(z, -1).permute(1, 0, 2, 3), v.permute(1, 0, 2, 3).squeeze(-1)
+        v_old = v_n[:, :-1] if value_clip else None
+        if fused:
+            assert ops.ppo_loss_prob_ok(prob, values_now)
+            la, lc = ops.ppo_loss_prob(prob, action, values_now, lp_old, adv, active, v_old, v_tgt, eps, coef, value_clip)
+        else:
+            dist = torch.distributions.Categorical(prob)
+            la, lc = ops.ppo_loss(dist.log_prob(action), dist.entropy(), values_now, lp_old, adv, active, v_old, v_tgt, eps, coef, value_clip)
+        (la + lc).backward()
+        res.append((la.detach(), lc.detach(), z.grad, v.grad))
+    torch.testing.assert_close(res[1][0], res[0][0], rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(res[1][1], res[0][1], rtol=2e-6, atol=1e-7)
+    scale = float(res[0][2].abs().max())
+    assert float((res[1][2] - res[0][2]).abs().max()) <= 2e-6 * scale + 1e-12, (float((res[1][2] - res[0][2]).abs().max()), scale)
+    assert torch.equal(res[1][3], res[0][3])
+
+
+@pytest.mark.gpu
 def test_msg_agg_empty_neighbourhoods():
     """Obstacle relation of an EMPTY map: kvalid == 0 (critic, rollout form) and an all-zero adjacency (actor) aggregate to
     exact zeros (F.normalize's 1e-12 clamp), with zero parameter gradients; mixed with rows that do have neighbours."""
