@@ -18,11 +18,15 @@
 // multiplies, as in k_sb_wgrad -- instead of all eight waves staging, then all multiplying;  4 = the ReLU-backward form of an input
 // gradient (sb_gemm_masked): `addend` is not added but read as a MASK -- outputs of the first mask_tiles 128-column blocks are kept
 // where it is positive, zeroed elsewhere -- and the column sums of the result (the bias gradient of the layer whose ReLU this is)
-// leave the kernel as one row of partial sums per workgroup (fixed order: k_sb_colsum_reduce adds them deterministically).
+// leave the kernel as one row of partial sums per workgroup (fixed order: k_sb_colsum_reduce adds them deterministically);
+// 8 = the kernel also writes the SIGN BITS of its result (bit k of byte j of a row: Y[row][8 j + k] > 0; two lanes' nibbles joined with
+// one shuffle, ybits rows ldyb bytes apart): behind a ReLU epilogue these are relu'(Y), and the backward's masked input gradient of the
+// layer that consumes Y (bit 16: with bit 4, `addend` is that byte matrix, lda its row stride in BYTES) reads 1 bit per element instead of
+// the 4-byte value.
 template <int KC, int NT, int OPT = 3>   // inputs / 32, outputs / 128
 __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__restrict__ X, int64_t ldx, const float *__restrict__ W, int64_t ldw,
                                                       const float *__restrict__ bias, const float *addend, int64_t lda, float *Y, int64_t ldy, int relu,
-                                                      int mask_tiles, float *__restrict__ colsum_part) {
+                                                      int mask_tiles, float *__restrict__ colsum_part, uint8_t *__restrict__ ybits = nullptr, int64_t ldyb = 0) {
     extern __shared__ uint4 sbg_tile[];                 // [buffer][piece][chunk][row half][lane]
     constexpr int IMG = 3 * KC * 2 * 64, UPW = KC / 4;  // uint4 per image; (chunk, half) blocks staged per wave and iteration
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 15, gq = l >> 4;
@@ -123,7 +127,19 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
         }
         if (!(OPT & 2) || w >= 4) next_tile();
         // D tile: lane (i, gq), register q -> output 16 (w + 8 t) + 4 gq + q of row i of the half
-        if constexpr ((OPT & 4) && !(OPT & 1)) {
+        unsigned mb[NT][2];
+        if constexpr ((OPT & 4) && (OPT & 16)) {
+            // relu' as bits: one byte per (tile, half) holds this lane's four (a nibble)
+            __builtin_amdgcn_sched_barrier(0);
+            const uint8_t *bits = (const uint8_t *)addend;
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) {
+                const int64_t row = it * 32 + rt * 16 + i;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    mb[t][rt] = row < R && t < mask_tiles ? (unsigned)bits[row * lda + 2 * (w + 8 * t) + (gq >> 1)] >> ((gq & 1) * 4) : 15u;
+            }
+        } else if constexpr ((OPT & 4) && !(OPT & 1)) {
             // the mask of the whole tile is requested at once, in registers the matrix phase has just released (the barrier keeps the
             // compiler from hoisting the loads into that phase, where they do not fit)
             __builtin_amdgcn_sched_barrier(0);
@@ -145,7 +161,10 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
                     float4 v;
                     if constexpr (OPT & 4) {
                         v = make_float4(acc[t][rt][0], acc[t][rt][1], acc[t][rt][2], acc[t][rt][3]);
-                        if (t < mask_tiles) {
+                        if constexpr (OPT & 16) {
+                            const unsigned m = mb[t][rt];
+                            v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+                        } else if (t < mask_tiles) {
                             v.x = a4[t][rt].x > 0.f ? v.x : 0.f; v.y = a4[t][rt].y > 0.f ? v.y : 0.f;
                             v.z = a4[t][rt].z > 0.f ? v.z : 0.f; v.w = a4[t][rt].w > 0.f ? v.w : 0.f;
                         }
@@ -157,6 +176,11 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
                             v.x += a4[t][rt].x; v.y += a4[t][rt].y; v.z += a4[t][rt].z; v.w += a4[t][rt].w;
                         }
                         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        if constexpr (OPT & 8) {   // lanes (i, gq) and (i, gq ^ 1) hold the two nibbles of a byte (same row: both are active here)
+                            const unsigned nib = (unsigned)(v.x > 0.f) | ((unsigned)(v.y > 0.f) << 1) | ((unsigned)(v.z > 0.f) << 2) | ((unsigned)(v.w > 0.f) << 3);
+                            const unsigned other = (unsigned)__shfl_xor((int)nib, 16);
+                            if (!(gq & 1)) ybits[row * ldyb + 2 * (w + 8 * t) + (gq >> 1)] = (uint8_t)(nib | (other << 4));
+                        }
                     }
                     *(float4 *)(Y + row * ldy + col) = v;
                 }
@@ -196,7 +220,8 @@ static int g_sbg_wgs_per_cu = 0;   // lab override (tools/microbench/sb_gemm_lab
 
 template <int KC, int NT, int OPT>
 int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
-                   float *Y, int64_t ldy, int relu, hipStream_t st, int mask_tiles = 0, float *colsum_part = nullptr, float *colsum = nullptr) {
+                   float *Y, int64_t ldy, int relu, hipStream_t st, int mask_tiles = 0, float *colsum_part = nullptr, float *colsum = nullptr,
+                   uint8_t *ybits = nullptr, int64_t ldyb = 0) {
     constexpr int lds = 2 * 3 * KC * 2 * 64 * 16;
     static std::once_flag once;   // the evaluator's thread may launch concurrently with the trainer's
     static hipError_t attr_rc = hipSuccess;
@@ -210,7 +235,7 @@ int launch_sb_gemm(int64_t R, const float *X, int64_t ldx, const float *W, int64
     const int wpc = g_sbg_wgs_per_cu ? g_sbg_wgs_per_cu : (KC * NT == 4 && R >= 131072 ? 2 : 1);
     const int grid = n_it < (int64_t)cus * wpc ? (int)n_it : cus * wpc;
     hipLaunchKernelGGL((k_sb_gemm_n128<KC, NT, OPT>), dim3(grid), dim3(512), lds, st, R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, mask_tiles,
-                       colsum_part);
+                       colsum_part, ybits, ldyb);
     if constexpr (OPT & 4) hipLaunchKernelGGL(k_sb_colsum_reduce, dim3((128 * NT + 127) / 128), dim3(128), 0, st, grid, 128 * NT, colsum_part, colsum);
     return (int)hipGetLastError();
 }
@@ -225,9 +250,14 @@ constexpr int SBG_MASK_OPT_256 = 6, SBG_MASK_OPT_384 = 4, SBG_MASK_OPT_K384 = 6;
 
 template <int KC, int NT>
 int launch_sb_gemm_best(int64_t R, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *addend, int64_t lda,
-                        float *Y, int64_t ldy, int relu, hipStream_t st) {
+                        float *Y, int64_t ldy, int relu, hipStream_t st, uint8_t *ybits = nullptr, int64_t ldyb = 0) {
     constexpr int PLAIN = (KC == 4 && NT == 1) ? 0 : 2;
     constexpr int ADD = KC == 12 ? 2 : (KC == 8 ? 3 : (NT == 3 ? 0 : 1));
+    if constexpr (NT == 1 && KC <= 8) if (ybits) {      // + the sign bits of Y (sb_gemm_signs): the same schedule, the bytes written beside the result
+        if (addend) return launch_sb_gemm<KC, NT, ADD | 8>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st, 0, nullptr, nullptr, ybits, ldyb);
+        if constexpr (KC == 4 && NT == 1) if (R >= 786432) return launch_sb_gemm<4, 1, 10>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st, 0, nullptr, nullptr, ybits, ldyb);
+        return launch_sb_gemm<KC, NT, PLAIN | 8>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st, 0, nullptr, nullptr, ybits, ldyb);
+    }
     if (addend) return launch_sb_gemm<KC, NT, ADD>(R, X, ldx, W, ldw, bias, addend, lda, Y, ldy, relu, st);
     // 128 x 128 beyond the Infinity Cache (the update's AGG layer over three relations, 1 476 000 rows): the phase shift wins there
     // (405 -> 341 us; at 492 000 rows 121 against 124)

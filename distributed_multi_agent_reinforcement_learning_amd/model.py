@@ -110,7 +110,7 @@ class DHGN(nn.Module):
         """hist: sequence of `depth` tensors (R,P,E), hop k = hist[k] (k = 0 is the most recent)."""
         if self.depth == 0:
             return h0
-        h, cat, link = h0, None, None
+        h, carry = h0, None
         for k in range(self.depth):
             aggk, fk = self.AGG_layers[f"AGG_fcra_{k}"], self.FCRA_layers[k]
             # matmul(normalize(adj or ones, p=1), hist[k]): one pass, the history slice read in place (hist is stored data)
@@ -118,9 +118,9 @@ class DHGN(nn.Module):
             last = k == self.depth - 1
             # FCRA_k([relu(AGG_k(nb)) | h]) as one K = 2E GEMM whose operand halves are written in place by their producers
             # (ops.fcra_hop); the last hop of a rollout lands in the static storage
-            # (each hop's output feeds the next hop only: `link` hands its relu' to that hop's input gradient)
-            h, cat, link = ops.fcra_hop(nb, h, cat, aggk.weight, aggk.bias, fk.weight, fk.bias, last, out if last else None, link)
-        h.relu_link = link       # for a caller that is the ONLY consumer of h (the update hands it to the first GRU layer)
+            # (each hop's output feeds the next hop only: `carry` hands its operand buffer and its relu' to that hop)
+            h, carry = ops.fcra_hop(nb, h, carry, aggk.weight, aggk.bias, fk.weight, fk.bias, last, out if last else None)
+        h.relu_link = carry[1]   # for a caller that is the ONLY consumer of h (the update hands it to the first GRU layer)
         return h
 
     def forward(self, p, e, o, adj_p, adj_e, adj_o, hist, is_critic, o_kvalid=None, q_div=1, out=None):

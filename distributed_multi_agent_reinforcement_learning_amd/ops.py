@@ -81,6 +81,8 @@ def load_library():
         L.wgrad_split_tn2.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, vp, vp]
         L.fcra_neighbour_mean.argtypes = [i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, vp, vp, i64, vp]
         L.fcra_neighbour_mean_multi.argtypes = [i32, vp, i32, i32, i32, i32, i64, i64, i64, i64, vp, i64, i32, i64, vp]
+        L.sb_gemm_signs.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp, i64, vp, i64, vp]
+        L.sb_gemm_masked_bits.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp]
         L.sb_gemm_masked_workspace.argtypes = [i32]
         L.sb_gemm_masked_workspace.restype = i64
         L.sb_gemm_masked.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp]
@@ -779,7 +781,7 @@ def linear_skinny(x, W, b=None):
     return F.linear(x, W, b)
 
 
-def _linear_fwd(x, W, b, out=None, relu=False, consume_addend=False):
+def _linear_fwd(x, W, b, out=None, relu=False, consume_addend=False, y_link=None):
     """x W^T + b; b is a bias (out,) or a full addend of the output's shape (the add rides in the GEMM epilogue, beta = 1);
     relu with a 1-D bias rides in the hipBLASLt epilogue as well (bit-identical to relu(linear)).
     consume_addend: the full addend b is a temporary the caller no longer needs -- the product accumulates INTO it
@@ -789,7 +791,10 @@ def _linear_fwd(x, W, b, out=None, relu=False, consume_addend=False):
     if out is None and x2.numel() and x2.stride(-1) == 1 and split_linear_ok(x2, W, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
         # the update's Linear layers on the split-bf16 kernel: bias / full addend / ReLU in its epilogue
         if b is None or b.dim() == 1:
-            return split_linear(x2, W, b, relu).view(oshape)
+            bits = None
+            if y_link is not None and relu and sign_bits_ok(W.shape[0], W.shape[1]):   # relu'(y) as bits for the consumer's backward
+                bits = y_link.bits = torch.empty((x2.shape[0], W.shape[0] // 8), dtype=torch.uint8, device=x2.device)
+            return split_linear(x2, W, b, relu, sign_bits=bits).view(oshape)
         if b.is_contiguous():
             b2 = b.view(-1, W.shape[0])
             if consume_addend:
@@ -832,7 +837,7 @@ class _Linear(torch.autograd.Function):
         inplace = bool(consume_addend and ctx.bias_kind == 2 and b.is_contiguous() and b.shape == x.shape[:-1] + (W.shape[0],))
         if inplace:
             ctx.mark_dirty(b)
-        y = _linear_fwd(x, W, b, None, relu, inplace)
+        y = _linear_fwd(x, W, b, None, relu, inplace, ctx.y_link if any(ctx.needs_input_grad) else None)
         ctx.save_for_backward(x, W, y if relu else None)
         return y
 
@@ -854,7 +859,10 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, W.shape[1])
         dx = None
         if ctx.needs_input_grad[0]:
-            fused = input_grad_masked(g2, W, x2, W.shape[1]) if ctx.x_link is not None else None
+            fused = None
+            if ctx.x_link is not None:
+                bits = ctx.x_link.bits
+                fused = input_grad_masked(g2, W, x2, W.shape[1], bits.view(x2.shape[0], -1) if bits is not None else None)
             if fused is not None:
                 dx, ctx.x_link.db = fused
             else:
@@ -884,10 +892,11 @@ class ReluLink:
     stores the column sums in `db` and returns the MASKED gradient, and the producer, finding `db` set, skips its own pass.  When the
     consumer cannot fuse (shape, mode), `db` stays None and both sides behave as without a link.  y must have no other consumer:
     autograd would add the other gradient to a masked one."""
-    __slots__ = ("db",)
+    __slots__ = ("db", "bits")
 
     def __init__(self):
         self.db = None
+        self.bits = None     # relu'(y) as sign bits (rows, width / 8) uint8 when the producer's GEMM wrote them (sb_gemm_signs), else None
 
     def take(self):
         db, self.db = self.db, None
@@ -896,13 +905,15 @@ class ReluLink:
 
 MASKED_GRAD_SHAPES = {(256, 128), (384, 128), (128, 384)}   # (inputs of the layer = columns of the gradient, outputs)
 MASKED_GRAD_MIN_ROWS = 4096
+RELU_BITS = os.environ.get("MAPPO_RELU_BITS", "1") != "0"   # A/B switch: off = the masked input gradients read the saved fp32 activations as mask
 RELU_LINK = os.environ.get("MAPPO_RELU_LINK", "1") != "0"   # A/B switch (tools/ab_switch.py): off = the separate relu' / bias-sum passes
 
 
-def input_grad_masked(g2, W, y, mask_cols):
+def input_grad_masked(g2, W, y, mask_cols, bits=None):
     """(g2 W) * (y > 0) on the first mask_cols columns, and the column sums of the result (include/mappo_ops.h sb_gemm_masked):
     the input gradient of a Linear layer (W: (outputs, inputs)) whose input y (rows, inputs) came out of a ReLU, with that ReLU's
-    backward and the bias gradient behind it.  -> (gradient (rows, inputs), sums (inputs,)), or None where the kernel does not apply."""
+    backward and the bias gradient behind it.  bits: (rows, inputs / 8) uint8 sign bits of y (sb_gemm_signs), read instead of y.
+    -> (gradient (rows, inputs), sums (inputs,)), or None where the kernel does not apply."""
     n_out, n_in = W.shape
     if (not RELU_LINK or PROJ_MODE != "split_bf16" or (n_in, n_out) not in MASKED_GRAD_SHAPES or not g2.is_cuda or g2.dim() != 2 or y.dim() != 2
             or g2.shape[0] < MASKED_GRAD_MIN_ROWS or y.shape != (g2.shape[0], n_in) or g2.dtype != torch.float32 or y.dtype != torch.float32):
@@ -916,6 +927,11 @@ def input_grad_masked(g2, W, y, mask_cols):
     out = torch.empty((R, n_in), dtype=torch.float32, device=g2.device)
     cs = torch.empty(n_in, dtype=torch.float32, device=g2.device)
     ws = torch.empty(L.sb_gemm_masked_workspace(n_in), dtype=torch.uint8, device=g2.device)
+    if bits is not None and RELU_BITS:
+        assert bits.dtype == torch.uint8 and bits.dim() == 2 and bits.shape == (R, n_in // 8) and bits.stride(1) == 1
+        _check(L.sb_gemm_masked_bits(R, n_in, n_out, _ptr(g2), g2.stride(0), _ptr(Wt), Wt.stride(0), _ptr(bits), bits.stride(0), int(mask_cols), _ptr(out),
+                                     out.stride(0), _ptr(cs), _ptr(ws), _stream()), "sb_gemm_masked_bits")
+        return out, cs
     _check(L.sb_gemm_masked(R, n_in, n_out, _ptr(g2), g2.stride(0), _ptr(Wt), Wt.stride(0), _ptr(y), y.stride(0), int(mask_cols), _ptr(out), out.stride(0),
                             _ptr(cs), _ptr(ws), _stream()), "sb_gemm_masked")
     return out, cs
@@ -994,11 +1010,15 @@ def block2d(t):
     return t.as_strided((t.numel() // E, E), (_vec_stride(t), 1))
 
 
-def _hop_gemm(x, W, b, out):
-    """relu(x W^T + b) into a column block: the split-bf16 kernel where the update routes its Linear layers to it, else hipBLASLt"""
+def _hop_gemm(x, W, b, out, sign_bits=None):
+    """relu(x W^T + b) into a column block: the split-bf16 kernel where the update routes its Linear layers to it, else hipBLASLt.
+    sign_bits: (rows, 16) uint8 block that receives relu'(result) as bits -> True when it was written (split kernel only)"""
     if split_linear_ok(x, W, out, mode=PROJ_MODE, shapes=UPDATE_SPLIT_SHAPES):
-        return split_linear(x, W, b, True, out=out)
-    return gemm_nt(x, W, b, True, out=out)
+        bits = sign_bits if sign_bits is not None and sign_bits_ok(W.shape[0], W.shape[1]) else None
+        split_linear(x, W, b, True, out=out, sign_bits=bits)
+        return bits is not None
+    gemm_nt(x, W, b, True, out=out)
+    return False
 
 
 class _FcraHop(torch.autograd.Function):
@@ -1011,26 +1031,35 @@ class _FcraHop(torch.autograd.Function):
     [d agg | d h], split-K MFMA weight gradients.  nb is stored data (no gradient)."""
 
     @staticmethod
-    def forward(ctx, nb, h, cat, Wagg, bagg, Wf, bf, last, out, box, h_link=None):
+    def forward(ctx, nb, h, cat, Wagg, bagg, Wf, bf, last, out, box, h_link=None, cat_bits=None):
         E = Wf.shape[0]
         rows = h.numel() // E
         nb2 = nb.reshape(rows, E)
+        train = any(ctx.needs_input_grad) and out is None
         if cat is None:
             cat = torch.empty((rows, 2 * E), dtype=h.dtype, device=h.device)
             cat[:, E:].copy_(block2d(h))
         else:
             assert cat.shape == (rows, 2 * E) and cat.is_contiguous() and h.data_ptr() == cat.data_ptr() + E * cat.element_size()
-        _hop_gemm(nb2, Wagg, bagg, cat[:, :E])
-        nxt = None
+        # relu' of this hop's operand [agg | h] as sign bits (rows, 2E / 8): the left half is written by the AGG GEMM here, the right half
+        # was written by the previous hop's FCRA GEMM (cat_bits); the backward's masked input gradient reads them instead of cat
+        if train and cat_bits is None:
+            cat_bits = torch.empty((rows, 2 * E // 8), dtype=torch.uint8, device=h.device)
+        ok_left = _hop_gemm(nb2, Wagg, bagg, cat[:, :E], cat_bits[:, :E // 8] if train else None)
+        nxt = nxt_bits = y_bits = None
         if out is not None:     # rollout: the caller's static storage (no autograd)
             ctx.mark_dirty(out)
             dst = block2d(out)
         elif last:
             dst = torch.empty((rows, E), dtype=h.dtype, device=h.device)
+            y_bits = torch.empty((rows, E // 8), dtype=torch.uint8, device=h.device) if train else None
         else:
             nxt = torch.empty((rows, 2 * E), dtype=h.dtype, device=h.device)
             dst = nxt[:, E:]
-        _hop_gemm(cat, Wf, bf, dst)
+            if train:
+                nxt_bits = torch.empty((rows, 2 * E // 8), dtype=torch.uint8, device=h.device)
+                y_bits = nxt_bits[:, E // 8:]
+        ok_y = _hop_gemm(cat, Wf, bf, dst, y_bits)
         box.append(nxt)
         ctx.save_for_backward(nb2, Wagg, Wf)
         # the two operand buffers are kept as plain references: the next hop writes the OTHER half of `nxt` in place, which bumps
@@ -1041,6 +1070,11 @@ class _FcraHop(torch.autograd.Function):
         # offer to whoever consumes this hop's output
         ctx.h_link, ctx.y_link = h_link, ReluLink()
         box.append(ctx.y_link)
+        # usable in backward when every masked half has its bits: the left one from this hop, the right one (if masked) from the previous hop
+        ctx.cat_bits = cat_bits if train and ok_left and (h_link is None or h_link.bits is not None) else None
+        if ok_y:
+            ctx.y_link.bits = y_bits
+        box.append(nxt_bits if ok_y else None)
         return dst.reshape(h.shape) if out is None else out
 
     @staticmethod
@@ -1059,7 +1093,7 @@ class _FcraHop(torch.autograd.Function):
             gin, dbf = relu_bwd_colsum(g2, y)
         # [d agg | d h]; relu' of the AGG layer -- and of the previous hop's FCRA layer, whose output the right half of cat is --
         # in the GEMM's epilogue, the two bias gradients its column sums
-        fused = input_grad_masked(gin, Wf, cat, 2 * E if ctx.h_link is not None else E)
+        fused = input_grad_masked(gin, Wf, cat, 2 * E if ctx.h_link is not None else E, ctx.cat_bits)
         if fused is not None:
             dcat, cs = fused
             ga, dbagg = dcat[:, :E], cs[:E]
@@ -1071,15 +1105,17 @@ class _FcraHop(torch.autograd.Function):
         dWf = wgrad(gin, cat)
         dWagg = wgrad(ga, nb2)
         d_h = dcat[:, E:].reshape(ctx.h_shape)         # a view (column block)
-        return None, d_h, None, dWagg, dbagg, dWf, dbf, None, None, None, None
+        return None, d_h, None, dWagg, dbagg, dWf, dbf, None, None, None, None, None
 
 
-def fcra_hop(nb, h, cat, Wagg, bagg, Wf, bf, last, out=None, h_link=None):
-    """-> (h', cat', link): see _FcraHop.  cat' is the buffer whose right half h' is (None after the last hop / when `out` is given);
-    link: the ReluLink of h' (pass it as h_link to the next hop, its only consumer)."""
+def fcra_hop(nb, h, carry, Wagg, bagg, Wf, bf, last, out=None):
+    """-> (h', carry'): see _FcraHop.  carry (None for the first hop) is what a hop hands to the next one, its only consumer: the buffer
+    whose right half h' is (None after the last hop / when `out` is given), the ReluLink of h', and the sign-bit block of that buffer;
+    carry'[1] is also the link for whoever consumes the last hop's output."""
+    cat, h_link, cat_bits = carry if carry is not None else (None, None, None)
     box = []
-    y = _FcraHop.apply(nb, h, cat, Wagg, bagg, Wf, bf, bool(last), out, box, h_link)
-    return y, box[0], box[1]
+    y = _FcraHop.apply(nb, h, cat, Wagg, bagg, Wf, bf, bool(last), out, box, h_link, cat_bits)
+    return y, (box[0], box[1], box[2])
 
 
 FUSED_CELL_MIN_ROWS = 1024  # single-step batches at least this large take the fused cell kernel
@@ -1372,7 +1408,7 @@ def split_linear_ok(x, W, out=None, addend=None, mode=None, shapes=None):
     return x.shape[1] == W.shape[1]
 
 
-def split_linear(x, W, bias=None, relu=False, out=None, addend=None):
+def split_linear(x, W, bias=None, relu=False, out=None, addend=None, sign_bits=None):
     """out = act(x W^T + bias + addend) for 2-D x (rows, K), W (N, K) with (N, K) in SPLIT_LINEAR_SHAPES, out / addend (rows, N), any
     row strides, in fp32 arithmetic on the bf16 matrix pipe (exact three-way operand splits, include/mappo_ops.h sb_gemm).  The
     rollout's Linear layers and the update's GRU input projections; no autograd.  addend may be out (accumulate in place)."""
@@ -1383,9 +1419,20 @@ def split_linear(x, W, bias=None, relu=False, out=None, addend=None):
     if out is None:
         out = torch.empty((R, N), dtype=torch.float32, device=x.device)
     b = bias.detach() if bias is not None else None
+    if sign_bits is not None:   # (rows, N / 8) uint8, possibly a column block of a wider byte matrix: relu'(out) for the backward (sb_gemm_signs)
+        assert sign_bits.dtype == torch.uint8 and sign_bits.shape == (R, N // 8) and sign_bits.stride(1) == 1 and sign_bits_ok(N, K)
+        _check(L.sb_gemm_signs(R, N, K, _ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), int(bool(relu)), _ptr(addend),
+                               addend.stride(0) if addend is not None else 0, _ptr(out), out.stride(0), _ptr(sign_bits), sign_bits.stride(0), _stream()),
+               "sb_gemm_signs")
+        return out
     _check(L.sb_gemm(R, N, K, _ptr(x), x.stride(0), _ptr(W), W.stride(0), _ptr(b), int(bool(relu)), _ptr(addend),
                      addend.stride(0) if addend is not None else 0, _ptr(out), out.stride(0), _stream()), "sb_gemm")
     return out
+
+
+def sign_bits_ok(N, K):
+    """the shapes whose split-bf16 GEMM can write relu'(result) as bits beside the result (ReluLink.bits)"""
+    return RELU_LINK and RELU_BITS and N == 128 and K in (128, 256)
 
 
 # the update's Linear layers, their input gradients and the GRU input projections gi = x W_ih^T + b_ih: the BLAS library | sb_gemm
@@ -1534,7 +1581,7 @@ class _GRULayerMulti(torch.autograd.Function):
             dx = None
             if ctx.needs_input_grad[4 + 6 * k]:
                 link = ctx.x_links[k] if ctx.x_links is not None else None
-                fused = input_grad_masked(dgi, w_ih, x2, I) if link is not None else None
+                fused = input_grad_masked(dgi, w_ih, x2, I, link.bits) if link is not None else None
                 if fused is not None:
                     dx, link.db = fused
                 else:

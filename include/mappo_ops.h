@@ -254,6 +254,11 @@ int sb_gemm_n128(int64_t R, int32_t K, const float *X, int64_t ldx, const float 
  * x W_ih^T + b_ih, (256, 128) the input gradient of an FCRA layer. */
 int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *C,
             int64_t ldc, float *Y, int64_t ldy, void *stream);
+/* sb_gemm (N = 128, K in {128, 256}) that also writes the sign bits of its result: y_sign_bits[row * ld_bytes + j], bit k = (Y[row][8 j + k] > 0),
+ * N / 8 bytes per row (rows ld_bytes apart: Y may be a column block of a wider matrix and the bytes a column block of its bit matrix).
+ * Behind the ReLU epilogue these are relu'(Y): sb_gemm_masked_bits reads them in the backward of the layer that consumes Y. */
+int sb_gemm_signs(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, int32_t relu, const float *C,
+                  int64_t ldc, float *Y, int64_t ldy, uint8_t *y_sign_bits, int64_t ld_bytes, void *stream);
 /* The input gradient of a Linear layer whose INPUT is the output of a ReLU layer, with that ReLU's backward and the bias gradient of
  * the layer in front of it in the same pass (autograd's threshold_backward + sum(0) of DHGN/mappo_parallel.py:148-233's relu(Linear)
  * chains):  Y = (X W^T) * (M > 0) on the first mask_cols columns (a multiple of 128; the others are plain X W^T),  colsum[N] = column
@@ -262,6 +267,9 @@ int sb_gemm(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const 
 int64_t sb_gemm_masked_workspace(int32_t N);
 int sb_gemm_masked(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const float *M, int64_t ldm,
                    int32_t mask_cols, float *Y, int64_t ldy, float *colsum, void *workspace, void *stream);
+/* The same with the mask as sign bits (sb_gemm_signs' layout, N / 8 bytes per row, row stride ld_bytes): 1 bit per element read instead of 4 bytes. */
+int sb_gemm_masked_bits(int64_t R, int32_t N, int32_t K, const float *X, int64_t ldx, const float *W, int64_t ldw, const uint8_t *sign_bits,
+                        int64_t ld_bytes, int32_t mask_cols, float *Y, int64_t ldy, float *colsum, void *workspace, void *stream);
 
 /*
  * PPO clipped-surrogate policy loss and clipped value loss of one mini-batch with their gradients

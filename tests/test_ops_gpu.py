@@ -1006,6 +1006,50 @@ def test_input_gradient_with_the_relu_backward_in_its_epilogue(n_in, n_out, mask
     assert float((dx.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
     assert float((cs.double() - ref.sum(0)).abs().max()) < 2e-6 * float(ref.abs().sum(0).max())
     assert torch.equal(dx, dx2) and torch.equal(cs, cs2)
+    # the same with relu'(y) given as sign bits (a column block of a wider byte matrix): identical results
+    packed = ((y > 0).view(R, n_in // 8, 8).to(torch.int32) * (1 << torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8)
+    wide = torch.full((R, n_in // 8 + 5), 0xA5, dtype=torch.uint8, device="cuda")
+    wide[:, 3:3 + n_in // 8] = packed
+    ops.set_matmul_mode("split_bf16")
+    try:
+        with torch.no_grad():
+            dxb, csb = ops.input_grad_masked(g, W, y, mask_cols, bits=wide[:, 3:3 + n_in // 8])
+    finally:
+        ops.restore_matmul_modes(modes)
+    assert torch.equal(dxb, dx) and torch.equal(csb, cs)
+
+
+@pytest.mark.parametrize("K,inplace", [(128, False), (256, False), (128, True)])
+def test_split_gemm_writes_the_sign_bits_of_its_result(K, inplace):
+    """sb_gemm_signs: relu(x W^T + b) [+ addend] into a column block, and bit k of byte j of a row = (result[row][8 j + k] > 0) into a
+    column block of a byte matrix -- the result equals the plain kernel's bit for bit, the bytes equal the packed comparison, the
+    neighbouring bytes and columns stay untouched; ragged row count."""
+    from distributed_multi_agent_reinforcement_learning_amd import ops
+    torch.manual_seed(K)
+    R, N = 40000 + 21, 128
+    x = torch.randn(R, K, device="cuda")
+    W, b = torch.randn(N, K, device="cuda") * 0.1, torch.randn(N, device="cuda") * 0.1
+    out_w = torch.full((R, 2 * N), 3.0, device="cuda")
+    ref_w = out_w.clone()
+    bits_w = torch.full((R, 32), 0x5A, dtype=torch.uint8, device="cuda")
+    if inplace:
+        out_w[:, N:] = torch.randn(R, N, device="cuda")
+        ref_w.copy_(out_w)
+    modes = ops.matmul_modes()
+    ops.set_matmul_mode("split_bf16")
+    try:
+        with torch.no_grad():
+            kw = dict(addend=out_w[:, N:]) if inplace else {}
+            ops.split_linear(x, W, None if inplace else b, True, out=out_w[:, N:], sign_bits=bits_w[:, 16:], **kw)
+            kw = dict(addend=ref_w[:, N:]) if inplace else {}
+            ops.split_linear(x, W, None if inplace else b, True, out=ref_w[:, N:], **kw)
+    finally:
+        ops.restore_matmul_modes(modes)
+    assert torch.equal(out_w, ref_w) and bool((out_w[:, :N] == 3.0).all())
+    y = out_w[:, N:]
+    packed = ((y > 0).view(R, N // 8, 8).to(torch.int32) * (1 << torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8)
+    assert torch.equal(bits_w[:, 16:], packed) and bool((bits_w[:, :16] == 0x5A).all())
+    assert 0.2 < float((y > 0).float().mean()) < 0.8
 
 
 def test_relu_link_gives_the_gradients_of_the_unlinked_layers():
@@ -1021,17 +1065,22 @@ def test_relu_link_gives_the_gradients_of_the_unlinked_layers():
     ops.set_matmul_mode("split_bf16")
     grads = {}
     try:
-        for linked in (False, True, "unused"):
+        for linked in (False, True, "unused", "fp32 mask"):
+            ops.RELU_BITS = linked != "fp32 mask"      # relu' from the sign bits the producer's GEMM wrote / from the saved activations
             Wa, ba, Ws = [t.clone().requires_grad_(True) for t in base]
             x = m3.clone().requires_grad_(True)
             link = ops.ReluLink() if linked else None
             emb = ops.linear(x, Wa, ba, relu=True, y_link=link)
-            h = ops.linear(emb.reshape(rows, 3 * E), Ws, None, x_link=link if linked is True else None)
+            h = ops.linear(emb.reshape(rows, 3 * E), Ws, None, x_link=link if linked in (True, "fp32 mask") else None)
+            assert link is None or (link.bits is not None) == ops.RELU_BITS
             (h * gout).sum().backward()
             grads[linked] = [t.grad for t in (Wa, ba, Ws, x)]
             assert link is None or link.db is None                               # consumed by the producer
     finally:
+        ops.RELU_BITS = True
         ops.restore_matmul_modes(modes)
+    for a, b in zip(grads[True], grads["fp32 mask"]):
+        assert torch.equal(a, b)
     for a, b, c in zip(grads[False], grads[True], grads["unused"]):
         assert torch.equal(a, c)
         assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), a.shape
@@ -1062,8 +1111,9 @@ def test_fcra_hop_forward_and_backward_match_f64(mode):
     modes = ops.matmul_modes()
     ops.set_matmul_mode(mode)
     try:
-        h1, cat1, link = ops.fcra_hop(nb[0], h0g, cat0, params[0], params[2], params[4], params[6], False)
-        h2, _, _ = ops.fcra_hop(nb[1], h1, cat1, params[1], params[3], params[5], params[7], True, h_link=link)
+        h1, carry = ops.fcra_hop(nb[0], h0g, (cat0, None, None), params[0], params[2], params[4], params[6], False)
+        cat1 = carry[0]
+        h2, _ = ops.fcra_hop(nb[1], h1, carry, params[1], params[3], params[5], params[7], True)
         (h2 * gout).sum().backward()
     finally:
         ops.restore_matmul_modes(modes)

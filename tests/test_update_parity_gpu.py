@@ -21,7 +21,7 @@ from tests.test_mappo_gpu import close, make_agent
 
 pytestmark = pytest.mark.gpu
 
-ENTRY_POINTS = ("wgrad_split_tn", "wgrad_tn", "relu_bwd_colsum", "wgrad_skinny", "sb_gemm", "sb_gemm_masked")
+ENTRY_POINTS = ("wgrad_split_tn", "wgrad_tn", "relu_bwd_colsum", "wgrad_skinny", "sb_gemm", "sb_gemm_masked", "sb_gemm_masked_bits", "sb_gemm_signs")
 
 
 @pytest.fixture
@@ -56,7 +56,9 @@ def _expected_entry_points(E, mode):
             want.add("sb_gemm")
     # ReLU backward + bias sums: in the input-gradient GEMM's epilogue (E = 128, split mode: every ReLU of the networks has such a
     # consumer), else the separate pass
-    want.add("sb_gemm_masked" if E == 128 and mode == "split_bf16" else "relu_bwd_colsum")
+    # consumer (E = 128, split mode: every ReLU of the networks has such a consumer; relu' travels as sign bits written by the ReLU
+    # layer's own GEMM), else the separate pass
+    want.update({"sb_gemm_masked_bits", "sb_gemm_signs"} if E == 128 and mode == "split_bf16" else {"relu_bwd_colsum"})
     return want
 
 
