@@ -9,7 +9,9 @@ shared by actor and critic during rollouts and the critic's all-ones
 slots in training only (Q5).
 """
 import contextlib
+import gc
 import logging
+import threading
 import types
 
 import numpy as np
@@ -482,6 +484,30 @@ class MAPPO:
         torch.save(self.critic.state_dict(), cwd + "critic.pth")
 
 
+_gc_lock, _gc_depth, _gc_was_on = threading.Lock(), 0, False
+
+
+@contextlib.contextmanager
+def _collector_paused():
+    """The cyclic collector must not run while a stream captures: what it frees may be another agent's graphs or their private pool, and
+    releasing those inside a capture aborts the process (torch.cuda.graph collects once on entry; an allocation-count threshold can still
+    trip mid-capture).  Nested / concurrent (the trainer's and the background evaluator's thread): the collector comes back when the last
+    capture has ended."""
+    global _gc_depth, _gc_was_on
+    with _gc_lock:
+        if _gc_depth == 0:
+            _gc_was_on = gc.isenabled()
+            gc.disable()
+        _gc_depth += 1
+    try:
+        yield
+    finally:
+        with _gc_lock:
+            _gc_depth -= 1
+            if _gc_depth == 0 and _gc_was_on:
+                gc.enable()
+
+
 class _RolloutState:
     """Static device storage of one lockstep rollout and the per-tick policy program on it.
 
@@ -655,18 +681,9 @@ class _RolloutState:
                 self.policy_step()
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        # The cyclic collector must not run while the stream captures: what it frees may be another agent's graphs or their private
-        # pool, and releasing those inside a capture aborts the process (torch.cuda.graph collects once on entry; an allocation-count
-        # threshold can still trip mid-capture).
-        import gc
-        gc_was_on = gc.isenabled()
-        gc.disable()
-        try:
+        with _collector_paused():
             with torch.cuda.graph(g, capture_error_mode="thread_local"):   # a background evaluator may launch on its own stream meanwhile
                 self.policy_step()
-        finally:
-            if gc_was_on:
-                gc.enable()
         for t, k in zip(live, keep):
             t.copy_(k)
         return g
