@@ -4,6 +4,10 @@
 
 #include "sb_common.hpp"
 
+#ifndef SBG_ABLATE
+#define SBG_ABLATE 0   // lab only (tools/microbench/sb_gemm_lab.hip): 1 = no matrix instructions, 2 = no result stores, 4 = no operand loads
+#endif
+
 // ---- Y = act(X W^T + b [+ C]) for 128 (384) outputs, fp32 arithmetic on the bf16 matrix pipe (k_sb_gemm_n128) ------------------
 // The rollout's Linear layers (DHGN AGG / semantic / FCRA layers, reference DHGN/mappo_parallel.py:148-233: 3e4-2e5 rows against a
 // 128 x {128, 256, 384} weight; and the update's GRU input projection, 384 x 128) on the exact three-way bf16 split of k_gru_cell_sb.
@@ -49,8 +53,12 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
             pf[n][0] = pf[n][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < R) {
                 const float *src = X + row * ldx + 32 * c + 8 * gq;
-                pf[n][0] = *(const float4 *)src;
-                pf[n][1] = *(const float4 *)(src + 4);
+                if constexpr (SBG_ABLATE & 4) {
+                    pf[n][0] = pf[n][1] = make_float4((float)row * 1e-6f, 0.5f, -0.25f, (float)c);
+                } else {
+                    pf[n][0] = *(const float4 *)src;
+                    pf[n][1] = *(const float4 *)(src + 4);
+                }
             }
         }
     };
@@ -121,7 +129,11 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
                 acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b0[pj]), acc[t][0], 0, 0, 0); \
                 acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wg[t][c][pi]), __builtin_bit_cast(bf16x8, b1[pj]), acc[t][1], 0, 0, 0); \
             }
-            SBG_MMA(2, 0) SBG_MMA(0, 2) SBG_MMA(1, 1) SBG_MMA(1, 0) SBG_MMA(0, 1) SBG_MMA(0, 0)
+            if constexpr (!(SBG_ABLATE & 1)) { SBG_MMA(2, 0) SBG_MMA(0, 2) SBG_MMA(1, 1) SBG_MMA(1, 0) SBG_MMA(0, 1) SBG_MMA(0, 0) }
+            else {
+#pragma unroll
+                for (int t = 0; t < NT; t++) { acc[t][0][0] += __uint_as_float(b0[0].x ^ wg[t][c][0].x); acc[t][1][1] += __uint_as_float(b1[2].y ^ wg[t][c][2].w); }
+            }
 #undef SBG_MMA
             if constexpr (AHEAD) __builtin_amdgcn_sched_barrier(0);
         }
@@ -182,7 +194,8 @@ __global__ __launch_bounds__(512) void k_sb_gemm_n128(int64_t R, const float *__
                             if (!(gq & 1)) ybits[row * ldyb + 2 * (w + 8 * t) + (gq >> 1)] = (uint8_t)(nib | (other << 4));
                         }
                     }
-                    *(float4 *)(Y + row * ldy + col) = v;
+                    if constexpr (SBG_ABLATE & 2) { if (v.x == 12345.678f) *(float4 *)(Y + row * ldy + col) = v; }
+                    else *(float4 *)(Y + row * ldy + col) = v;
                 }
             }
         }
