@@ -147,6 +147,14 @@ template <int EV> __device__ __forceinline__ FV<EV> fv_relu(const FV<EV> &a) {
     for (int e = 0; e < EV; e++) r.v[e] = fmaxf(a.v[e], 0.f);
     return r;
 }
+// two features per lane as ONE 64-bit value: the compiler then keeps the pair in an aligned register pair and issues the packed fp32
+// instructions (v_pk_add_f32 / v_pk_fma_f32: two lanes' worth per issue) for the differences as well as the sums
+typedef float msg_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ msg_f2 fv2(const FV<2> &a) { return (msg_f2){a.v[0], a.v[1]}; }
+__device__ __forceinline__ FV<2> fv2(msg_f2 x) { FV<2> r; r.v[0] = x.x; r.v[1] = x.y; return r; }
+__device__ __forceinline__ FV<2> operator+(const FV<2> &a, const FV<2> &b) { return fv2(fv2(a) + fv2(b)); }
+__device__ __forceinline__ FV<2> operator-(const FV<2> &a, const FV<2> &b) { return fv2(fv2(a) - fv2(b)); }
+__device__ __forceinline__ FV<2> fv_relu(const FV<2> &a) { return fv2(__builtin_elementwise_max(fv2(a), (msg_f2){0.f, 0.f})); }
 template <int EV> __device__ __forceinline__ FV<EV> fv_load(const float *p, int f, int stride) {
     FV<EV> r;
 #pragma unroll
