@@ -385,7 +385,7 @@ class MAPPO:
                 xs += [emb_a.reshape(rows, self.actor.rnn_input_dim), emb_c.reshape(rows, self.critic.rnn_input_dim)]
                 links += [getattr(emb_a, "relu_link", None), getattr(emb_c, "relu_link", None)]   # depth > 0: the last hop's ReLU
             h0s = [torch.zeros(m.num_layers, x.shape[0] // T, H, dtype=x.dtype, device=x.device) for x, m in zip(xs, mods)]
-            feats = ops.gru_multi(xs, h0s, mods, agents=P, steps=T, grouped=True, x_links=links)
+            feats = ops.gru_multi(xs, h0s, mods, agents=P, steps=T, grouped=True, x_links=links, zero_state=True)
             losses = []
             for k, (n0, n1) in enumerate(group):
                 mb = n1 - n0

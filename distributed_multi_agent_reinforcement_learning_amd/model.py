@@ -360,7 +360,7 @@ def sequence_forward_pair(actor, critic, obs, hist_a, hist_c, batch, steps):
         h0 = [torch.zeros(m.num_layers, batch * P, m.rnn_hidden_dim, dtype=emb_a.dtype, device=emb_a.device) for m in (actor, critic)]
         fa, fc = ops.gru_multi([emb_a.reshape(batch * steps * P, actor.rnn_input_dim), emb_c.reshape(batch * steps * P, critic.rnn_input_dim)],
                                h0, [actor.GRU, critic.GRU], agents=P, steps=steps,
-                               x_links=[getattr(emb_a, "relu_link", None), getattr(emb_c, "relu_link", None)])
+                               x_links=[getattr(emb_a, "relu_link", None), getattr(emb_c, "relu_link", None)], zero_state=True)
         feat_a, feat_c = fa.reshape(steps, batch, P, actor.rnn_hidden_dim), fc.reshape(steps, batch, P, critic.rnn_hidden_dim)
     return pair_heads(actor, critic, feat_a, feat_c)
 

@@ -1505,10 +1505,12 @@ class _GRULayerMulti(torch.autograd.Function):
     inputs, own number of sequences; same T and row order) with the recurrences of all of them in ONE persistent launch each way
     (gru_seq_fwd_multi / gru_seq_bwd_multi); per network the arithmetic is that of _GRULayer's persistent path.
     args: T, Bs (sequences per network), agents, x_links (None, or per network the ReluLink of an input that came out of a ReLU and
-    feeds this layer only -- its relu' and bias sum then ride in the input gradient), then per network (x, h0, w_ih, w_hh, b_ih, b_hh)."""
+    feeds this layer only -- its relu' and bias sum then ride in the input gradient), zero_h0 (the caller vouches that every h0 is all
+    zeros -- the update's sequences start from the zero state: the first step then adds nothing to dW_hh), then per network
+    (x, h0, w_ih, w_hh, b_ih, b_hh)."""
 
     @staticmethod
-    def forward(ctx, T, Bs, agents, x_links, *ts):
+    def forward(ctx, T, Bs, agents, x_links, zero_h0, *ts):
         L = load_library()
         n = len(ts) // 6
         H = ts[3].shape[1]
@@ -1535,7 +1537,7 @@ class _GRULayerMulti(torch.autograd.Function):
             saved += [x, h0, w_ih, whh, out, save]
         _seq_fwd(L, arr, n, T, max(Bs), H, int(agents))
         ctx.dims, ctx.agents, ctx.n = (T, tuple(Bs)), int(agents), n
-        ctx.x_links = x_links
+        ctx.x_links, ctx.zero_h0 = x_links, bool(zero_h0)
         ctx.x_shapes = [ts[6 * k].shape for k in range(n)]
         if need:
             ctx.save_for_backward(*saved)
@@ -1569,17 +1571,17 @@ class _GRULayerMulti(torch.autograd.Function):
             a.B = B
             per.append((dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws))
         _seq_bwd(L, arr, n, T, max(Bs), H, ctx.agents)
-        grads = [None, None, None, None]
+        grads = [None, None, None, None, None]
         for k in range(n):
             x, h0, w_ih, w_hh, out, save = sv[6 * k: 6 * k + 6]
             dout, dgi, dgh, dnr, dh0, db_ih, db_hh, ws = per[k]
             B = Bs[k]
-            dw_hh = _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H)
+            dw_hh = _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H, ctx.zero_h0)
             I = x.shape[-1]
             x2 = x.reshape(T * B, I)
             dw_ih = wgrad(dgi, x2)
             dx = None
-            if ctx.needs_input_grad[4 + 6 * k]:
+            if ctx.needs_input_grad[5 + 6 * k]:
                 link = ctx.x_links[k] if ctx.x_links is not None else None
                 fused = input_grad_masked(dgi, w_ih, x2, I, link.bits) if link is not None else None
                 if fused is not None:
@@ -1591,9 +1593,9 @@ class _GRULayerMulti(torch.autograd.Function):
         return tuple(grads)
 
 
-def _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H):
+def _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H, zero_h0=False):
     """dW_hh = [dr dz dnr]^T h_prev over all steps: from the full time-major dgh, or (dr, dz stored once) from dgi's first 2H
-    columns and dnr"""
+    columns and dnr.  zero_h0: h0 is known to be all zeros (the first step's term vanishes: two small library products less)."""
     if dgh is not None:
         dw_hh = torch.mm(dgh[0].t(), h0)
         if T > 1:
@@ -1601,28 +1603,35 @@ def _gru_dw_hh(dgi, dgh, dnr, out, h0, T, B, H):
         return dw_hh
     dw_hh = torch.empty((3 * H, H), dtype=dgi.dtype, device=dgi.device)
     drz, hp = dgi[:, :2 * H], out[:-1].reshape((T - 1) * B, H)     # (dr, dz): a column slice of dgi, rows strided, no copy
-    torch.mm(drz[:B].t(), h0, out=dw_hh[:2 * H])
-    torch.mm(dnr[0].t(), h0, out=dw_hh[2 * H:])
+    acc = True
+    if zero_h0 and T > 1:
+        acc = False                                                # the products below write dw_hh instead of adding to the first step's
+    elif zero_h0:
+        dw_hh.zero_()
+    else:
+        torch.mm(drz[:B].t(), h0, out=dw_hh[:2 * H])
+        torch.mm(dnr[0].t(), h0, out=dw_hh[2 * H:])
     if T > 1:
         a1, a2 = drz[B:], dnr[1:].reshape((T - 1) * B, H)
         if WGRAD_MODE == "split_bf16" and H == 128 and _wgrad_ok(a1, hp) and _wgrad_ok(a2, hp):
             # [dr dz | dnr]^T h_prev in ONE pass over h_prev (k_sb_wgrad with its left operand in two tensors)
             L = load_library()
             ws = torch.empty(L.wgrad_split_workspace(3 * H, H), dtype=torch.uint8, device=dgi.device)
-            _check(L.wgrad_split_tn2(a1.shape[0], 2 * H, H, H, _ptr(a1), a1.stride(0), _ptr(a2), a2.stride(0), _ptr(hp), hp.stride(0), _ptr(dw_hh), 1,
+            _check(L.wgrad_split_tn2(a1.shape[0], 2 * H, H, H, _ptr(a1), a1.stride(0), _ptr(a2), a2.stride(0), _ptr(hp), hp.stride(0), _ptr(dw_hh), int(acc),
                                      _ptr(ws), _stream()), "wgrad_split_tn2")
         else:
-            wgrad(a1, hp, out=dw_hh[:2 * H], accumulate=True)
-            wgrad(a2, hp, out=dw_hh[2 * H:], accumulate=True)
+            wgrad(a1, hp, out=dw_hh[:2 * H], accumulate=acc)
+            wgrad(a2, hp, out=dw_hh[2 * H:], accumulate=acc)
     return dw_hh
 
 
-def gru_multi(xs, h0s, modules, agents=0, steps=None, grouped=False, x_links=None):
+def gru_multi(xs, h0s, modules, agents=0, steps=None, grouped=False, x_links=None, zero_state=False):
     """ops.gru for several independent GRU modules of one architecture (actor and critic, for one or -- `grouped` -- several
     mini-batches: the inputs may differ in their number of sequences): layer by layer, the recurrences of all of them in one launch
     (see _GRULayerMulti).  `modules` need only carry num_layers and the weight_* / bias_* attributes of torch.nn.GRU.  Returns the
     list of outputs (T, B_k, H) (no h_n: sequences start from the given h0 and the final state is out[-1]).  Shapes the persistent
-    kernels do not cover take ops.gru per module.  x_links: per input its ReluLink or None (see _GRULayerMulti)."""
+    kernels do not cover take ops.gru per module.  x_links: per input its ReluLink or None; zero_state: every h0 is all zeros (see
+    _GRULayerMulti)."""
     n = len(xs)
     if agents:
         assert xs[0].dim() == 2 and steps and all(x.shape[0] % (steps * agents) == 0 for x in xs)
@@ -1646,7 +1655,7 @@ def gru_multi(xs, h0s, modules, agents=0, steps=None, grouped=False, x_links=Non
             ts += [inps[k], h0s[k][layer], getattr(m, f"weight_ih_l{layer}"), getattr(m, f"weight_hh_l{layer}"),
                    getattr(m, f"bias_ih_l{layer}"), getattr(m, f"bias_hh_l{layer}")]
         links = tuple(x_links) if layer == 0 and x_links is not None and any(l is not None for l in x_links) else None
-        inps = list(_GRULayerMulti.apply(T, tuple(Bs), int(agents) if layer == 0 else 0, links, *ts))
+        inps = list(_GRULayerMulti.apply(T, tuple(Bs), int(agents) if layer == 0 else 0, links, bool(zero_state), *ts))
     return inps
 
 

@@ -850,13 +850,13 @@ def test_gru_multi_grouped_ragged_equals_separate_calls():
     gouts = [torch.randn(T, n * P, E, device="cuda") for n in ns]
     h0s = [torch.zeros(2, n * P, E, device="cuda") for n in ns]
     res = []
-    for multi in (False, True):
+    for multi in (False, True, "zero state"):
         xs = [e.clone().requires_grad_(True) for e in embs]
         for m in mods:
             m.zero_grad()
         ms = [mods[w] for w in which]
-        if multi:
-            outs = ops.gru_multi(xs, h0s, ms, agents=P, steps=T, grouped=True)
+        if multi:   # ("zero state": the caller vouches for h0 == 0 and the first step's term of dW_hh is not computed: adding exact zeros or not)
+            outs = ops.gru_multi(xs, h0s, ms, agents=P, steps=T, grouped=True, zero_state=multi == "zero state")
         else:
             outs = [ops.gru(x, h, m, agents=P, steps=T)[0] for x, h, m in zip(xs, h0s, ms)]
         # per input its own backward root, like the mini-batches' losses
@@ -866,6 +866,8 @@ def test_gru_multi_grouped_ragged_equals_separate_calls():
         assert torch.equal(a, b)
     for a, b in zip(res[0][2], res[1][2]):                    # three inputs accumulate into one module's gradient: order of the sum
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(res[1][0] + res[1][1] + res[1][2], res[2][0] + res[2][1] + res[2][2]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("B", [32768, 4096, 1030])
