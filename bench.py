@@ -563,6 +563,14 @@ def main():
             out["dominant_kernel"] = {"kernel": dom["kernel"], "us_per_launch": dom["us_per_launch"], "launches_per_iteration": int(2 * main_res.get("epochs", 1)),
                                       "bound": "hbm (5 120 B per sequence row and step) beside the matrix pipe", "frac_of_hbm": dom["frac_of_hbm"],
                                       "frac_of_matrix_pipe": dom["frac"], "matrix_pipe_peak_TFLOPs": dom["peak"]}
+            try:              # HBM bytes per launch from the committed PMC record of this kernel (tools/pmc_gru_traffic.py), if its shape is the probe's
+                rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_gru_traffic.json")))
+                k = [r for r in rec["kernels"] if r["kernel"] == "k_gru_seq_bwd_sb"]
+                if k and abs(k[0]["algorithmic_bytes"] - 5120.0 * dom.get("rows", 0) * dom.get("steps", 0)) < 1:
+                    out["dominant_kernel"]["traffic"] = k[0]["fetch_bytes_x2"] + k[0]["write_bytes"]
+                    out["dominant_kernel"]["algorithmic_bytes"] = k[0]["algorithmic_bytes"]
+            except (OSError, ValueError, KeyError):
+                pass
         if second is not None:
             out["configs"] = {"cfg3": {k: second[k] for k in ("value", "ms_per_step", "ppo_updates_per_s", "breakdown_ms", "hbm_peak_GB", "workload", "roofline_iteration")}}
         if fp32_run is not None:
