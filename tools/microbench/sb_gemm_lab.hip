@@ -356,6 +356,19 @@ int main(int argc, char **argv) {
                 }
                 CK(hipFree(part)); CK(hipFree(cs));
             }
+            // the ReLU layers' variant that also writes relu'(Y) as sign bits (OPT bit 8) beside the plain kernel
+            if (N == 128 && (K == 128 || K == 256)) {
+                uint8_t *bits;
+                CK(hipMalloc(&bits, (size_t)R * 16));
+                auto plain = [&] { return K == 128 ? (R >= 786432 ? launch_sb_gemm<4, 1, 2>(R, X, K, W, K, B, nullptr, 0, Y, N, 1, 0) : launch_sb_gemm<4, 1, 0>(R, X, K, W, K, B, nullptr, 0, Y, N, 1, 0))
+                                                   : launch_sb_gemm<8, 1, 2>(R, X, K, W, K, B, nullptr, 0, Y, N, 1, 0); };
+                auto signs = [&] { return K == 128 ? (R >= 786432 ? launch_sb_gemm<4, 1, 10>(R, X, K, W, K, B, nullptr, 0, Y, N, 1, 0, 0, nullptr, nullptr, bits, 16)
+                                                                   : launch_sb_gemm<4, 1, 8>(R, X, K, W, K, B, nullptr, 0, Y, N, 1, 0, 0, nullptr, nullptr, bits, 16))
+                                                   : launch_sb_gemm<8, 1, 10>(R, X, K, W, K, B, nullptr, 0, Y, N, 1, 0, 0, nullptr, nullptr, bits, 16); };
+                const float us_p = time_us(plain), us_s = time_us(signs);
+                printf("N=%d K=%d rows=%lld  relu layer: plain %8.1f us, with sign bits of the result %8.1f us\n", N, K, (long long)R, us_p, us_s);
+                CK(hipFree(bits));
+            }
             // in place accumulate (beta = 1) through the product entry point
             CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(B)); CK(hipFree(Y)); CK(hipFree(C));
         }
